@@ -1,0 +1,45 @@
+"""Loader for the committed golden fixtures (tests/golden/*.npz, written by
+tools/gen_golden.py from the compiled reference) and the input recipes that go
+with them.  Data only; numpy.load without pickle."""
+import os
+
+import numpy as np
+
+from simdcomp_amd import synth
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+FULL_LENGTHS = [0, 1, 2, 3, 4, 5, 7, 8, 31, 32, 33, 127, 128, 129, 130, 255, 257]
+DIGEST_LENGTHS = [1000, 4095, 9999]
+PACK_NAMES = ["simdpack", "simdpackwithoutmask", "simdpackd1", "simdpackwithoutmaskd1", "simdpackFOR"]
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+def length_input(n, bit, kind):
+    if kind == 0:
+        return synth.random_bits(500 + bit, n, bit)
+    return synth.rand_u32(600 + bit, n)
+
+
+def corpus_plain(bit, masked, nblk):
+    return synth.random_bits(700, nblk * 128, bit) if not masked else synth.rand_u32(701, nblk * 128)
+
+
+def corpus_d1(bit, nblk):
+    v = synth.sorted_gaps(710 + bit, nblk * 128, bit, first=99)
+    return v, synth.block_offsets(v, 17)
+
+
+def corpus_for(bit, nblk):
+    return synth.clustered(720 + bit, nblk, bit)
+
+
+def corpus_mixed(nblk):
+    widths = synth.skewed_widths(730, nblk, 1, 20)
+    gaps = synth.rand_u32(731, nblk * 128).reshape(nblk, 128)
+    m = ((np.uint64(1) << widths.astype(np.uint64)) - np.uint64(1)).astype(np.uint32)
+    gaps = (gaps & m[:, None]).reshape(-1).astype(np.uint64)
+    v = (np.cumsum(gaps) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    return v, synth.block_offsets(v, 0)
