@@ -1,0 +1,81 @@
+/*
+ * simdcomp.h -- drop-in declarations of lemire/simdcomp's 128-integer block
+ * codec API, implemented by libsimdcomp_hip.so on an AMD MI355X.
+ *
+ * A program written against the reference's umbrella header
+ * (include/simdcomp.h:8-21 there) compiles against this one unchanged and links
+ * with -lsimdcomp_hip instead of -lsimdcomp.  Pointers are HOST pointers, as in
+ * the reference; every data-touching routine stages its operands to the GPU,
+ * runs the HIP kernel and copies the result back before returning, so results
+ * are bit-identical to the reference's but a single 128-integer call costs a
+ * kernel launch plus two PCIe copies.  Callers with many blocks should use the
+ * *_length routines here (pipelined in 64 MiB pieces) or, better, keep data on
+ * the device and call the batched entry points of simdcomp_hip.h.
+ *
+ * Differences a caller can observe, all outside the reference's contract:
+ *   - if no usable GPU is present, or a HIP call fails, the routine prints the
+ *     HIP error to stderr and aborts (the reference API has no error channel);
+ *   - calls are serialised on an internal lock (the reference is re-entrant);
+ *   - simdpackFOR / simdunpackFOR accept unaligned pointers (the reference's
+ *     need 16-byte alignment, src/simdfor.c:32,418).
+ *
+ * Each prototype cites the reference declaration it replaces.
+ */
+#ifndef SIMDCOMP_H_
+#define SIMDCOMP_H_
+
+#include <emmintrin.h> /* __m128i: the compressed stream is addressed in 16-byte vectors */
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { SIMDBlockSize = 128 }; /* include/simdcomputil.h:22 */
+
+/* ---- include/simdcomputil.h ------------------------------------------------ */
+uint32_t bits(const uint32_t v);                                        /* :14 */
+uint32_t maxbits(const uint32_t *begin);                                /* :17 */
+uint32_t maxbits_length(const uint32_t *in, uint32_t length);           /* :20 */
+uint32_t simdmin(const uint32_t *in);                                   /* :25 */
+uint32_t simdmin_length(const uint32_t *in, uint32_t length);           /* :28 */
+void simdmaxmin_length(const uint32_t *in, uint32_t length, uint32_t *getmin, uint32_t *getmax); /* :33 */
+void simdmaxmin(const uint32_t *in, uint32_t *getmin, uint32_t *getmax);                         /* :37 */
+uint32_t simdmaxbitsd1(uint32_t initvalue, const uint32_t *in);                                  /* :43 */
+uint32_t simdmaxbitsd1_length(uint32_t initvalue, const uint32_t *in, uint32_t length);          /* :47 */
+
+/* ---- include/simdbitpacking.h ---------------------------------------------- */
+void simdpack(const uint32_t *in, __m128i *out, const uint32_t bit);             /* :24 */
+void simdpackwithoutmask(const uint32_t *in, __m128i *out, const uint32_t bit);  /* :28 */
+void simdunpack(const __m128i *in, uint32_t *out, const uint32_t bit);           /* :31 */
+int simdpack_compressedbytes(int length, const uint32_t bit);                    /* :35 */
+__m128i *simdpack_length(const uint32_t *in, size_t length, __m128i *out, const uint32_t bit);         /* :43 */
+const __m128i *simdunpack_length(const __m128i *in, size_t length, uint32_t *out, const uint32_t bit); /* :51 */
+__m128i *simdpack_shortlength(const uint32_t *in, int length, __m128i *out, const uint32_t bit);       /* :60 */
+const __m128i *simdunpack_shortlength(const __m128i *in, int length, uint32_t *out,
+                                      const uint32_t bit);                                             /* :68 */
+void simdfastset(__m128i *in128, uint32_t b, uint32_t value, size_t index);                            /* :73 */
+
+/* ---- include/simdintegratedbitpacking.h ------------------------------------ */
+void simdpackd1(uint32_t initvalue, const uint32_t *in, __m128i *out, const uint32_t bit);            /* :24 */
+void simdpackwithoutmaskd1(uint32_t initvalue, const uint32_t *in, __m128i *out, const uint32_t bit); /* :30 */
+void simdunpackd1(uint32_t initvalue, const __m128i *in, uint32_t *out, const uint32_t bit);          /* :34 */
+
+/* ---- include/simdfor.h ------------------------------------------------------ */
+void simdpackFOR(uint32_t initvalue, const uint32_t *in, __m128i *out, const uint32_t bit);   /* :20 */
+void simdunpackFOR(uint32_t initvalue, const __m128i *in, uint32_t *out, const uint32_t bit); /* :24 */
+int simdpackFOR_compressedbytes(int length, const uint32_t bit);                              /* :29 */
+__m128i *simdpackFOR_length(uint32_t initvalue, const uint32_t *in, int length, __m128i *out,
+                            const uint32_t bit);                                              /* :35 */
+const __m128i *simdunpackFOR_length(uint32_t initvalue, const __m128i *in, int length, uint32_t *out,
+                                    const uint32_t bit);                                      /* :42 */
+uint32_t simdselectFOR(uint32_t initvalue, const __m128i *in, uint32_t bit, int slot);        /* :48 */
+void simdfastsetFOR(uint32_t initvalue, __m128i *in, uint32_t bit, uint32_t value, size_t index); /* :53 */
+int simdsearchwithlengthFOR(uint32_t initvalue, const __m128i *in, uint32_t bit, int length, uint32_t key,
+                            uint32_t *presult);                                               /* :65 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIMDCOMP_H_ */

@@ -1,0 +1,162 @@
+/*
+ * simdcomp_hip.h -- batched, device-pointer C ABI of the MI355X block codec.
+ *
+ * Every entry point is the "many blocks per call" form of one routine of
+ * lemire/simdcomp's C API; the comment on each names the reference routine
+ * (file:line under the reference tree) whose per-block behaviour it reproduces
+ * bit for bit.  The compressed layout is the reference's own: b 16-byte vectors
+ * per 128-integer block, four interleaved lanes (include/simdcomputil.h:22,
+ * src/simdbitpacking.c:217-323).
+ *
+ * Conventions
+ *   - all d_* pointers are DEVICE pointers on the current HIP device;
+ *     integer arrays and payloads must be 16-byte aligned, per-block payload
+ *     offsets are byte offsets and must be multiples of 16;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls
+ *     only enqueue work, they never synchronise, allocate or free;
+ *   - sizes are size_t (the reference's int lengths overflow at 2^30 values);
+ *   - return value: 0 on success, a positive hipError_t if a HIP call failed,
+ *     or one of the negative SIMDCOMP_HIP_E* codes for a rejected argument.
+ *     The reference has no error channel (bit > 32 silently does nothing,
+ *     src/simdbitpacking.c:14046); here bit > 32 is SIMDCOMP_HIP_EBIT.
+ *   - a block's "initvalue" is the reference's initvalue argument: the
+ *     differential seed for the d1 routines, the frame base for the FOR ones.
+ */
+#ifndef SIMDCOMP_HIP_H_
+#define SIMDCOMP_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SIMDCOMP_HIP_OK 0
+#define SIMDCOMP_HIP_EBIT (-1)   /* bit width > 32 */
+#define SIMDCOMP_HIP_EALIGN (-2) /* pointer or offset not 16-byte aligned */
+#define SIMDCOMP_HIP_ENULL (-3)  /* required pointer is NULL */
+#define SIMDCOMP_HIP_EMODE (-4)  /* unknown mode */
+#define SIMDCOMP_HIP_ESIZE (-5)  /* size beyond what the entry point supports */
+
+#define SIMDCOMP_HIP_PLAIN 0 /* simdpack / simdunpack family */
+#define SIMDCOMP_HIP_D1 1    /* simdpackd1 / simdunpackd1 family */
+#define SIMDCOMP_HIP_FOR 2   /* simdpackFOR / simdunpackFOR family */
+
+/* Library version (major*10000 + minor*100 + patch). */
+int simdcomp_hip_version(void);
+/* Text of the most recent failure on the calling thread ("" if none). */
+const char *simdcomp_hip_last_error(void);
+
+/* ---- uniform width: block k's payload starts at d_out + k*16*bit ---------- */
+
+/* nblocks x simdpack (masked != 0, src/simdbitpacking.c:14052) or
+ * simdpackwithoutmask (masked == 0, src/simdbitpacking.c:13913). */
+int simdcomp_hip_pack(const uint32_t *d_in, void *d_out, size_t nblocks, uint32_t bit, int masked,
+                      void *stream);
+/* nblocks x simdunpack (src/simdbitpacking.c:13773). */
+int simdcomp_hip_unpack(const void *d_in, uint32_t *d_out, size_t nblocks, uint32_t bit, void *stream);
+
+/* nblocks x simdpackd1 (masked, src/simdintegratedbitpacking.c:25198) or
+ * simdpackwithoutmaskd1 (:25058).  d_initvalues[k] seeds block k.  If
+ * d_initvalues is NULL the blocks are chained the way example.c:63-71 does it:
+ * block 0 starts from `initvalue`, block k from d_in[128k-1]; `initvalue` is
+ * ignored otherwise.  d_initvalues_out (optional) receives the seed used for
+ * each block, i.e. the array simdcomp_hip_unpackd1 needs. */
+int simdcomp_hip_packd1(uint32_t initvalue, const uint32_t *d_initvalues, const uint32_t *d_in, void *d_out,
+                        size_t nblocks, uint32_t bit, int masked, uint32_t *d_initvalues_out, void *stream);
+/* nblocks x simdunpackd1 (src/simdintegratedbitpacking.c:24915); block k is
+ * decoded from seed d_initvalues[k], no block depends on another. */
+int simdcomp_hip_unpackd1(const uint32_t *d_initvalues, const void *d_in, uint32_t *d_out, size_t nblocks,
+                          uint32_t bit, void *stream);
+
+/* nblocks x simdpackFOR (src/simdfor.c:14705), frame base d_initvalues[k]. */
+int simdcomp_hip_packFOR(const uint32_t *d_initvalues, const uint32_t *d_in, void *d_out, size_t nblocks,
+                         uint32_t bit, void *stream);
+/* nblocks x simdunpackFOR (src/simdfor.c:14846). */
+int simdcomp_hip_unpackFOR(const uint32_t *d_initvalues, const void *d_in, uint32_t *d_out, size_t nblocks,
+                           uint32_t bit, void *stream);
+
+/* ---- per-block widths: the caller convention of example.c:56-75,135-150 ----
+ * d_bits[k] is block k's width, d_payload_offsets[k] the byte offset of its
+ * payload inside d_payload (see simdcomp_hip_payload_offsets).  mode is one of
+ * SIMDCOMP_HIP_PLAIN / _D1 / _FOR; masked and the initvalue arguments are as in
+ * the uniform calls (FOR ignores masked). */
+int simdcomp_hip_pack_mixed(int mode, int masked, uint32_t initvalue, const uint32_t *d_initvalues,
+                            const uint32_t *d_in, void *d_payload, const uint64_t *d_payload_offsets,
+                            const uint8_t *d_bits, size_t nblocks, uint32_t *d_initvalues_out, void *stream);
+int simdcomp_hip_unpack_mixed(int mode, const uint32_t *d_initvalues, const void *d_payload,
+                              const uint64_t *d_payload_offsets, const uint8_t *d_bits, uint32_t *d_out,
+                              size_t nblocks, void *stream);
+
+/* ---- per-block reductions -------------------------------------------------- */
+
+/* d_bits[k] = maxbits(block k) (src/simdcomputil.c:42). */
+int simdcomp_hip_maxbits(const uint32_t *d_in, size_t nblocks, uint8_t *d_bits, void *stream);
+/* d_bits[k] = simdmaxbitsd1(seed k, block k) (src/simdcomputil.c:181); seeds as
+ * in simdcomp_hip_packd1 (explicit array, or chained from the input). */
+int simdcomp_hip_maxbitsd1(uint32_t initvalue, const uint32_t *d_initvalues, const uint32_t *d_in,
+                           size_t nblocks, uint8_t *d_bits, uint32_t *d_initvalues_out, void *stream);
+/* simdmaxmin per block (src/simdcomputil.c:95): d_min[k], d_max[k] (either may
+ * be NULL) and, if d_bits is given, d_bits[k] = bits(max - min), the frame
+ * width a FOR caller picks (tests/unit.c:659-666). */
+int simdcomp_hip_maxmin(const uint32_t *d_in, size_t nblocks, uint32_t *d_min, uint32_t *d_max,
+                        uint8_t *d_bits, void *stream);
+
+/* Whole-array reductions behind maxbits_length (src/simdcomputil.c:160),
+ * simdmaxbitsd1_length (:198), simdmin_length (:109) and simdmaxmin_length
+ * (:130): d_result4[0] = OR of the values, [1] = OR of successive differences
+ * seeded by initvalue, [2] = minimum, [3] = maximum (an empty array gives
+ * 0, 0, 0xFFFFFFFF, 0).  bits() of [0] / [1] are the two widths.  d_in needs
+ * only 4-byte alignment. */
+int simdcomp_hip_reduce_length(const uint32_t *d_in, size_t length, uint32_t initvalue, uint32_t *d_result4,
+                               void *stream);
+
+/* Exclusive prefix sum of 16*d_bits[k] -> d_payload_offsets[k]; *d_total_bytes
+ * (optional) receives the payload size.  d_workspace must hold
+ * simdcomp_hip_payload_offsets_workspace(nblocks) bytes. */
+size_t simdcomp_hip_payload_offsets_workspace(size_t nblocks);
+int simdcomp_hip_payload_offsets(const uint8_t *d_bits, size_t nblocks, uint64_t *d_payload_offsets,
+                                 uint64_t *d_total_bytes, void *d_workspace, void *stream);
+
+/* ---- arbitrary lengths (device-resident forms of the *_length routines) ---- */
+
+/* simdpack_compressedbytes / simdpackFOR_compressedbytes
+ * (src/simdbitpacking.c:14370, src/simdfor.c:15034) in size_t arithmetic. */
+size_t simdcomp_hip_compressedbytes(size_t length, uint32_t bit);
+/* simdpack_length (src/simdbitpacking.c:14379): whole blocks masked, the
+ * remainder through the unmasked short packer; writes
+ * simdcomp_hip_compressedbytes(length, bit) bytes. */
+int simdcomp_hip_pack_length(const uint32_t *d_in, size_t length, void *d_out, uint32_t bit, void *stream);
+/* simdunpack_length (src/simdbitpacking.c:14390). */
+int simdcomp_hip_unpack_length(const void *d_in, size_t length, uint32_t *d_out, uint32_t bit, void *stream);
+/* simdpackFOR_length (src/simdfor.c:15043): one frame base for the whole array.
+ * carry_in != 0 says that d_in[-4..-1] hold the row that precedes this piece of
+ * a longer array (used when an array is packed piecewise; 0 for a whole array). */
+int simdcomp_hip_packFOR_length(uint32_t initvalue, const uint32_t *d_in, size_t length, void *d_out,
+                                uint32_t bit, int carry_in, void *stream);
+/* simdunpackFOR_length (src/simdfor.c:15098). */
+int simdcomp_hip_unpackFOR_length(uint32_t initvalue, const void *d_in, size_t length, uint32_t *d_out,
+                                  uint32_t bit, void *stream);
+
+/* ---- block-range partitioner and verification reduction -------------------- */
+
+/* Contiguous block range of shard `part` out of `nparts`: blocks are
+ * independent (src/simdbitpacking.c:14382-14386 carries no state), so a corpus
+ * is split by block index.  Host-side arithmetic only. */
+int simdcomp_hip_partition(size_t nblocks, int nparts, int part, size_t *first, size_t *count);
+/* Same, but balanced on payload+output bytes for mixed widths.  h_payload_offsets
+ * is a HOST array of nblocks+1 byte offsets (last entry = total). */
+int simdcomp_hip_partition_by_bytes(const uint64_t *h_payload_offsets, size_t nblocks, int nparts, int part,
+                                    size_t *first, size_t *count);
+/* d_acc[0] += position-sensitive 64-bit checksum of d_data[0..nwords) (word i
+ * is hashed with global index index0+i, so shard sums add up to the checksum of
+ * the whole array); if d_other is given, d_acc[1] += number of words that
+ * differ from d_other.  d_acc is 2 x uint64 on the device, caller-zeroed. */
+int simdcomp_hip_checksum(const uint32_t *d_data, const uint32_t *d_other, size_t nwords, uint64_t index0,
+                          uint64_t *d_acc, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIMDCOMP_HIP_H_ */

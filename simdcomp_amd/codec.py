@@ -1,0 +1,207 @@
+"""Thin torch-tensor front end over the batched C ABI (include/simdcomp_hip.h).
+
+torch is used for device memory and streams only.  Integer arrays are int32
+tensors holding the uint32 bit patterns (torch has no first-class uint32),
+payloads and widths are uint8 tensors, payload offsets int64 tensors holding
+uint64 byte offsets.  Function names follow the reference's API; each call
+enqueues one kernel on the current torch stream.
+"""
+import torch
+
+from . import binding as B
+
+
+def _i32(x):
+    assert x.dtype == torch.int32 and x.is_cuda and x.is_contiguous()
+    return x
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _s32(v):
+    """uint32 value -> python int accepted by c_uint32."""
+    return int(v) & 0xFFFFFFFF
+
+
+def compressedbytes(length, bit):
+    return int(B.lib().simdcomp_hip_compressedbytes(length, bit))
+
+
+def pack(x, bit, masked=False, out=None):
+    """nblocks x simdpack / simdpackwithoutmask at one width."""
+    x = _i32(x)
+    nblocks = x.numel() // 128
+    if out is None:
+        out = torch.empty(nblocks * 16 * bit, dtype=torch.uint8, device=x.device)
+    B.check(B.lib().simdcomp_hip_pack(B.ptr(x), B.ptr(out), nblocks, bit, int(masked), _stream()), "pack")
+    return out
+
+
+def unpack(payload, nblocks, bit, out=None):
+    if out is None:
+        out = torch.empty(nblocks * 128, dtype=torch.int32, device=payload.device)
+    B.check(B.lib().simdcomp_hip_unpack(B.ptr(payload), B.ptr(out), nblocks, bit, _stream()), "unpack")
+    return out
+
+
+def packd1(x, bit, initvalues=None, initvalue=0, masked=False, out=None, initvalues_out=None):
+    x = _i32(x)
+    nblocks = x.numel() // 128
+    if out is None:
+        out = torch.empty(nblocks * 16 * bit, dtype=torch.uint8, device=x.device)
+    B.check(B.lib().simdcomp_hip_packd1(_s32(initvalue), B.ptr(initvalues), B.ptr(x), B.ptr(out), nblocks, bit,
+                                        int(masked), B.ptr(initvalues_out), _stream()), "packd1")
+    return out
+
+
+def unpackd1(initvalues, payload, nblocks, bit, out=None):
+    if out is None:
+        out = torch.empty(nblocks * 128, dtype=torch.int32, device=payload.device)
+    B.check(B.lib().simdcomp_hip_unpackd1(B.ptr(initvalues), B.ptr(payload), B.ptr(out), nblocks, bit, _stream()),
+            "unpackd1")
+    return out
+
+
+def packFOR(base, x, bit, out=None):
+    x = _i32(x)
+    nblocks = x.numel() // 128
+    if out is None:
+        out = torch.empty(nblocks * 16 * bit, dtype=torch.uint8, device=x.device)
+    B.check(B.lib().simdcomp_hip_packFOR(B.ptr(base), B.ptr(x), B.ptr(out), nblocks, bit, _stream()), "packFOR")
+    return out
+
+
+def unpackFOR(base, payload, nblocks, bit, out=None):
+    if out is None:
+        out = torch.empty(nblocks * 128, dtype=torch.int32, device=payload.device)
+    B.check(B.lib().simdcomp_hip_unpackFOR(B.ptr(base), B.ptr(payload), B.ptr(out), nblocks, bit, _stream()),
+            "unpackFOR")
+    return out
+
+
+def maxbits(x):
+    x = _i32(x)
+    nblocks = x.numel() // 128
+    out = torch.empty(nblocks, dtype=torch.uint8, device=x.device)
+    B.check(B.lib().simdcomp_hip_maxbits(B.ptr(x), nblocks, B.ptr(out), _stream()), "maxbits")
+    return out
+
+
+def maxbitsd1(x, initvalues=None, initvalue=0, initvalues_out=None):
+    x = _i32(x)
+    nblocks = x.numel() // 128
+    out = torch.empty(nblocks, dtype=torch.uint8, device=x.device)
+    B.check(B.lib().simdcomp_hip_maxbitsd1(_s32(initvalue), B.ptr(initvalues), B.ptr(x), nblocks, B.ptr(out),
+                                           B.ptr(initvalues_out), _stream()), "maxbitsd1")
+    return out
+
+
+def maxmin(x, want_bits=True):
+    x = _i32(x)
+    nblocks = x.numel() // 128
+    lo = torch.empty(nblocks, dtype=torch.int32, device=x.device)
+    hi = torch.empty(nblocks, dtype=torch.int32, device=x.device)
+    bits = torch.empty(nblocks, dtype=torch.uint8, device=x.device) if want_bits else None
+    B.check(B.lib().simdcomp_hip_maxmin(B.ptr(x), nblocks, B.ptr(lo), B.ptr(hi), B.ptr(bits), _stream()), "maxmin")
+    return lo, hi, bits
+
+
+def reduce_length(x, length=None, initvalue=0):
+    """-> int32[4] tensor: OR of values, OR of differences, min, max."""
+    n = x.numel() if length is None else length
+    out = torch.empty(4, dtype=torch.int32, device=x.device)
+    B.check(B.lib().simdcomp_hip_reduce_length(B.ptr(x), n, _s32(initvalue), B.ptr(out), _stream()), "reduce_length")
+    return out
+
+
+def payload_offsets(bits):
+    """Exclusive scan of 16*bits -> (int64 offsets tensor, total bytes as a 1-element int64 tensor)."""
+    nblocks = bits.numel()
+    off = torch.empty(nblocks, dtype=torch.int64, device=bits.device)
+    total = torch.zeros(1, dtype=torch.int64, device=bits.device)
+    ws = torch.empty(max(8, B.lib().simdcomp_hip_payload_offsets_workspace(nblocks)), dtype=torch.uint8,
+                     device=bits.device)
+    B.check(B.lib().simdcomp_hip_payload_offsets(B.ptr(bits), nblocks, B.ptr(off), B.ptr(total), B.ptr(ws),
+                                                 _stream()), "payload_offsets")
+    return off, total
+
+
+def pack_mixed(mode, x, bits, offsets, payload, initvalues=None, initvalue=0, masked=False, initvalues_out=None):
+    x = _i32(x)
+    nblocks = x.numel() // 128
+    B.check(B.lib().simdcomp_hip_pack_mixed(mode, int(masked), _s32(initvalue), B.ptr(initvalues), B.ptr(x),
+                                            B.ptr(payload), B.ptr(offsets), B.ptr(bits), nblocks,
+                                            B.ptr(initvalues_out), _stream()), "pack_mixed")
+    return payload
+
+
+def unpack_mixed(mode, payload, bits, offsets, nblocks, initvalues=None, out=None):
+    if out is None:
+        out = torch.empty(nblocks * 128, dtype=torch.int32, device=payload.device)
+    B.check(B.lib().simdcomp_hip_unpack_mixed(mode, B.ptr(initvalues), B.ptr(payload), B.ptr(offsets), B.ptr(bits),
+                                              B.ptr(out), nblocks, _stream()), "unpack_mixed")
+    return out
+
+
+def pack_length(x, bit, out=None):
+    x = _i32(x)
+    n = x.numel()
+    if out is None:
+        out = torch.empty(compressedbytes(n, bit), dtype=torch.uint8, device=x.device)
+    B.check(B.lib().simdcomp_hip_pack_length(B.ptr(x), n, B.ptr(out), bit, _stream()), "pack_length")
+    return out
+
+
+def unpack_length(payload, n, bit, out=None):
+    if out is None:
+        out = torch.empty(n, dtype=torch.int32, device=payload.device)
+    B.check(B.lib().simdcomp_hip_unpack_length(B.ptr(payload), n, B.ptr(out), bit, _stream()), "unpack_length")
+    return out
+
+
+def packFOR_length(base, x, bit, out=None):
+    x = _i32(x)
+    n = x.numel()
+    if out is None:
+        out = torch.empty(compressedbytes(n, bit), dtype=torch.uint8, device=x.device)
+    B.check(B.lib().simdcomp_hip_packFOR_length(_s32(base), B.ptr(x), n, B.ptr(out), bit, 0, _stream()),
+            "packFOR_length")
+    return out
+
+
+def unpackFOR_length(base, payload, n, bit, out=None):
+    if out is None:
+        out = torch.empty(n, dtype=torch.int32, device=payload.device)
+    B.check(B.lib().simdcomp_hip_unpackFOR_length(_s32(base), B.ptr(payload), n, B.ptr(out), bit, _stream()),
+            "unpackFOR_length")
+    return out
+
+
+def checksum(data, other=None, index0=0, acc=None):
+    """acc[0] += checksum(data), acc[1] += #words differing from other; returns acc (int64[2])."""
+    if acc is None:
+        acc = torch.zeros(2, dtype=torch.int64, device=data.device)
+    nwords = data.numel() * data.element_size() // 4
+    B.check(B.lib().simdcomp_hip_checksum(B.ptr(data), B.ptr(other), nwords, index0, B.ptr(acc), _stream()),
+            "checksum")
+    return acc
+
+
+def partition(nblocks, nparts, part):
+    import ctypes as C
+
+    first, count = C.c_size_t(), C.c_size_t()
+    B.check(B.lib().simdcomp_hip_partition(nblocks, nparts, part, C.byref(first), C.byref(count)), "partition")
+    return first.value, count.value
+
+
+def partition_by_bytes(h_offsets, nparts, part):
+    """h_offsets: numpy uint64 array of nblocks+1 byte offsets (host)."""
+    import ctypes as C
+
+    first, count = C.c_size_t(), C.c_size_t()
+    B.check(B.lib().simdcomp_hip_partition_by_bytes(B.ptr(h_offsets), len(h_offsets) - 1, nparts, part,
+                                                    C.byref(first), C.byref(count)), "partition_by_bytes")
+    return first.value, count.value

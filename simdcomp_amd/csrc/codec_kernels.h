@@ -1,0 +1,60 @@
+// Internal interface between the kernel translation unit and the C-ABI layers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace sc {
+
+enum { MODE_PLAIN = 0, MODE_D1 = 1, MODE_FOR = 2 };
+enum { RED_MAXBITS = 0, RED_MAXBITSD1 = 1, RED_MINMAX = 2 };
+
+struct UnpackArgs {
+  const void *payload;     // 16-byte aligned
+  const uint64_t *off;     // per-block payload byte offsets (multiples of 16) or null: block k at k*16*bit
+  const uint8_t *bits;     // per-block widths or null: uniform `bit`
+  const uint32_t *seeds;   // per-block d1 offset / FOR base or null: `seed0` for every block
+  uint32_t *out;
+  size_t nblocks;
+  size_t length;           // TAIL kernels: number of valid integers
+  uint32_t bit;
+  uint32_t seed0;
+};
+
+struct PackArgs {
+  const uint32_t *in;
+  void *payload;
+  const uint64_t *off;
+  const uint8_t *bits;
+  const uint32_t *seeds;   // d1: null = chain from the input (block k seeded by in[128k-1], block 0 by seed0)
+  uint32_t *seeds_out;     // d1: optional, receives the seed used for every block
+  size_t nblocks;
+  size_t length;           // GENERIC kernels: number of valid integers
+  uint32_t bit;
+  uint32_t seed0;
+  int carry_blocks;        // GENERIC: hand the end-of-block spill to the next block (whole-array generic loop)
+  int carry_first;         // GENERIC: block 0 also receives a spill, from the row stored just before `in`
+};
+
+struct ReduceArgs {
+  const uint32_t *in;
+  const uint32_t *seeds;
+  uint32_t *seeds_out;
+  uint8_t *bits_out;
+  uint32_t *min_out;
+  uint32_t *max_out;
+  size_t nblocks;
+  uint32_t seed0;
+};
+
+hipError_t launch_unpack(int mode, bool runtime_width, bool tail, const UnpackArgs &a, hipStream_t st);
+hipError_t launch_pack(int mode, bool masked, bool runtime_width, bool generic, const PackArgs &a, hipStream_t st);
+hipError_t launch_reduce(int what, const ReduceArgs &a, hipStream_t st);
+size_t scan_workspace_bytes(size_t nblocks);
+hipError_t launch_payload_offsets(const uint8_t *bits, size_t nblocks, uint64_t *off, uint64_t *total,
+                                  void *workspace, hipStream_t st);
+hipError_t launch_reduce_array(const uint32_t *in, size_t length, uint32_t init, uint32_t *result4, hipStream_t st);
+hipError_t launch_checksum(const uint32_t *data, const uint32_t *other, size_t nwords, uint64_t index0,
+                           uint64_t *acc, hipStream_t st);
+
+}  // namespace sc

@@ -1,0 +1,702 @@
+// Device kernels for the 128-integer block bit-packing codec (gfx950 / CDNA4).
+//
+// Wire format (identical to lemire/simdcomp, include/simdcomputil.h:22 and the
+// schedule visible at src/simdbitpacking.c:217-323): value i of a block lives in
+// lane i&3, row k = i>>2; a lane is a bit stream in which row k occupies bits
+// [k*b, k*b+b); word w of lane l is stored at uint32 index 4*w+l, so "vector" w
+// (16 bytes) holds word w of all four lanes.  A block is b vectors.
+//
+// Thread mapping used by every kernel here: one block per 32-lane half of a
+// wave64, thread k of the half owns row k (the four values 4k..4k+3, one from
+// each lane, one 16-byte access on the integer side).  A 256-thread workgroup
+// therefore covers 8 blocks per step and runs U steps per loop iteration with
+// all of their global loads issued up front.
+//
+//   unpack: the half-wave's b payload vectors are fetched by its first b
+//           threads with one coalesced 16-byte load each, staged in a
+//           wave-private LDS slot, and every thread then reads the one or two
+//           vectors that hold its row (word extraction through LDS); a funnel
+//           shift (v_alignbit_b32) + mask yields the four values.  No
+//           workgroup barrier: a wave only ever reads what it wrote itself.
+//   d1:     running sum = 3 adds inside the thread + a 32-lane inclusive scan
+//           of the per-thread totals done with DPP row_shr:1/2/4/8 and
+//           row_bcast:15 restricted to rows 1 and 3 (so nothing leaks from one
+//           half-wave's block into the other's), seeded by the block offset.
+//   pack:   every thread shifts its row into place, receives the spill of the
+//           previous row through DPP wave_shr:1, and a segmented OR-scan over
+//           the threads that share an output word (again DPP row_shr +
+//           row_bcast:15) leaves the finished word in the last thread of each
+//           segment, which stores it.  No LDS, no barrier.
+//
+// All arithmetic is uint32 mod 2^32.  Memory-bound: no MFMA anywhere.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <utility>
+
+#include "codec_kernels.h"
+
+namespace sc {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118;
+constexpr int DPP_ROW_BCAST15 = 0x142;
+constexpr int DPP_WAVE_SHR1 = 0x138;
+
+// Lane l receives `v` from the lane the DPP control names, or 0 where that lane
+// does not exist / the row is masked off.
+template <int CTRL, int ROWMASK = 0xF>
+__device__ __forceinline__ uint32_t dpp0(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWMASK, 0xF, false);
+}
+
+__device__ __forceinline__ uint32_t field_mask(uint32_t b) { return (uint32_t)((1ull << b) - 1ull); }
+
+__device__ __forceinline__ uint32_t funnel(uint32_t hi, uint32_t lo, uint32_t s) {
+  return __builtin_amdgcn_alignbit(hi, lo, s);  // ({hi,lo} >> (s & 31))[31:0]
+}
+
+// Inclusive sum over the 32 lanes of each half-wave.
+__device__ __forceinline__ uint32_t half_scan_add(uint32_t t) {
+  t += dpp0<DPP_ROW_SHR1>(t);
+  t += dpp0<DPP_ROW_SHR2>(t);
+  t += dpp0<DPP_ROW_SHR4>(t);
+  t += dpp0<DPP_ROW_SHR8>(t);
+  t += dpp0<DPP_ROW_BCAST15, 0xA>(t);
+  return t;
+}
+
+// Wave-private LDS hand-off: LDS instructions of one wave execute in order, so
+// only the compiler has to be kept from moving accesses across this point.
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+constexpr int BLOCKS_PER_STEP = 8;  // 256 threads = 8 half-waves
+
+// ---------------------------------------------------------------------------
+// unpack
+// ---------------------------------------------------------------------------
+// B >= 0: width fixed at compile time (uniform batches); B < 0: per-block width
+// from a.bits (or the uniform a.bit), decided per half-wave at run time.
+// TAIL: the last block may hold fewer than 128 values (a.length counts values);
+// only rows/values that exist are read and written.
+template <int B, int MODE, int U, bool TAIL>
+__global__ __launch_bounds__(256) void k_unpack(UnpackArgs a) {
+  __shared__ u32x4 lds[4][2][33];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int h = lane >> 5, k = lane & 31;
+  u32x4 *slot = lds[wv][h];
+  const u32x4 *payload = reinterpret_cast<const u32x4 *>(a.payload);
+  const size_t per_iter = (size_t)BLOCKS_PER_STEP * U;
+  const size_t ntiles = (a.nblocks + per_iter - 1) / per_iter;
+
+  for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const size_t first = tile * per_iter + (size_t)wv * 2 * U + h;
+    size_t blk[U];
+    bool valid[U];
+    uint32_t b[U], seed[U];
+    size_t vbase[U];
+    u32x4 ld[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      blk[u] = first + 2 * (size_t)u;
+      valid[u] = blk[u] < a.nblocks;
+      if constexpr (B >= 0) {
+        b[u] = B;
+      } else {
+        b[u] = a.bits ? (valid[u] ? a.bits[blk[u]] : 0u) : a.bit;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      vbase[u] = a.off ? (valid[u] ? (size_t)(a.off[blk[u]] >> 4) : 0) : blk[u] * (size_t)b[u];
+      if constexpr (MODE != MODE_PLAIN) {
+        seed[u] = a.seeds ? (valid[u] ? a.seeds[blk[u]] : 0u) : a.seed0;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      ld[u] = u32x4{0, 0, 0, 0};
+      uint32_t nvec = b[u];
+      if constexpr (TAIL) {
+        const size_t start = blk[u] * 128;
+        const size_t nval = start < a.length ? (a.length - start < 128 ? a.length - start : 128) : 0;
+        nvec = (uint32_t)((((nval + 3) / 4) * b[u] + 31) / 32);
+      }
+      if (valid[u] && (uint32_t)k < nvec) ld[u] = payload[vbase[u] + k];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      u32x4 v;
+      if constexpr (B == 0) {
+        v = u32x4{0, 0, 0, 0};
+      } else if constexpr (B == 32) {
+        v = ld[u];
+      } else {
+        wave_lds_fence();
+        if ((uint32_t)k < b[u]) slot[k] = ld[u];
+        wave_lds_fence();
+        const uint32_t p = (uint32_t)k * b[u], w = p >> 5, s = p & 31;
+        const u32x4 lo = slot[w], hi = slot[w + 1];
+        const uint32_t m = field_mask(b[u]);
+        v.x = funnel(hi.x, lo.x, s) & m;
+        v.y = funnel(hi.y, lo.y, s) & m;
+        v.z = funnel(hi.z, lo.z, s) & m;
+        v.w = funnel(hi.w, lo.w, s) & m;
+      }
+      if constexpr (MODE == MODE_D1) {
+        // running sum over the block, seeded by the block offset; a 32-bit wide
+        // block holds raw values and is left alone
+        u32x4 r = v;
+        r.y += r.x;
+        r.z += r.y;
+        r.w += r.z;
+        const uint32_t incl = half_scan_add(r.w);
+        const uint32_t before = seed[u] + incl - r.w;
+        r.x += before;
+        r.y += before;
+        r.z += before;
+        r.w += before;
+        if (B == 32 || (B < 0 && b[u] == 32)) r = v;
+        v = r;
+      } else if constexpr (MODE == MODE_FOR) {
+        if (!(B == 32 || (B < 0 && b[u] == 32))) {
+          v.x += seed[u];
+          v.y += seed[u];
+          v.z += seed[u];
+          v.w += seed[u];
+        }
+      }
+      if (valid[u]) {
+        uint32_t *o = a.out + blk[u] * 128 + 4 * k;
+        if constexpr (TAIL) {
+          const size_t idx = blk[u] * 128 + 4 * (size_t)k;
+          if (idx + 4 <= a.length) {
+            *reinterpret_cast<u32x4 *>(o) = v;
+          } else {
+            if (idx + 0 < a.length) o[0] = v.x;
+            if (idx + 1 < a.length) o[1] = v.y;
+            if (idx + 2 < a.length) o[2] = v.z;
+          }
+        } else {
+          *reinterpret_cast<u32x4 *>(o) = v;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// pack
+// ---------------------------------------------------------------------------
+constexpr int max_rows_per_word(int b) { return b <= 0 ? 32 : (32 + b - 1) / b; }
+
+// GENERIC reproduces the reference's arbitrary-length packer
+// (src/simdbitpacking.c:14190 simdpack_shortlength, src/simdfor.c:15043
+// simdpackFOR_length): values past a.length are padding (0, or the frame base),
+// a field that ends exactly on a word boundary still hands value >> b to the
+// next word (visible only for out-of-range input), that hand-over also crosses
+// from one block to the next, and only the vectors that hold bits are written.
+template <int B, int MODE, bool MASKED, int U, bool GENERIC>
+__global__ __launch_bounds__(256) void k_pack(PackArgs a) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int h = lane >> 5, k = lane & 31;
+  u32x4 *payload = reinterpret_cast<u32x4 *>(a.payload);
+  const size_t per_iter = (size_t)BLOCKS_PER_STEP * U;
+  const size_t ntiles = (a.nblocks + per_iter - 1) / per_iter;
+
+  for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const size_t first = tile * per_iter + (size_t)wv * 2 * U + h;
+    size_t blk[U];
+    bool valid[U];
+    uint32_t b[U], seed[U];
+    size_t vbase[U];
+    u32x4 x[U], carry[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      blk[u] = first + 2 * (size_t)u;
+      valid[u] = blk[u] < a.nblocks;
+      if constexpr (B >= 0) {
+        b[u] = B;
+      } else {
+        b[u] = a.bits ? (valid[u] ? a.bits[blk[u]] : 0u) : a.bit;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      vbase[u] = a.off ? (valid[u] ? (size_t)(a.off[blk[u]] >> 4) : 0) : blk[u] * (size_t)b[u];
+      seed[u] = a.seed0;
+      if constexpr (MODE == MODE_D1) {
+        // explicit per-block offsets, or the chained stream of example.c:63-71:
+        // block 0 starts from seed0, block k from the last value of block k-1
+        if (a.seeds) {
+          if (valid[u]) seed[u] = a.seeds[blk[u]];
+        } else if (valid[u] && blk[u] > 0) {
+          seed[u] = a.in[blk[u] * 128 - 1];
+        }
+      } else if constexpr (MODE == MODE_FOR) {
+        if (a.seeds && valid[u]) seed[u] = a.seeds[blk[u]];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t idx = blk[u] * 128 + 4 * (size_t)k;
+      x[u] = u32x4{0, 0, 0, 0};
+      carry[u] = u32x4{0, 0, 0, 0};
+      if constexpr (GENERIC) {
+        const uint32_t pad = (MODE == MODE_FOR) ? seed[u] : 0u;
+        x[u] = u32x4{pad, pad, pad, pad};
+        if (valid[u]) {
+          if (idx + 4 <= a.length) {
+            x[u] = *reinterpret_cast<const u32x4 *>(a.in + idx);
+          } else {
+            if (idx + 0 < a.length) x[u].x = a.in[idx + 0];
+            if (idx + 1 < a.length) x[u].y = a.in[idx + 1];
+            if (idx + 2 < a.length) x[u].z = a.in[idx + 2];
+          }
+          // last row of the previous block: its fields end on the block's final
+          // word boundary and hand value >> b to this block's first word
+          if (k == 0 && (blk[u] > 0 || a.carry_first) && a.carry_blocks) carry[u] = *reinterpret_cast<const u32x4 *>(a.in + idx - 4);
+        }
+      } else {
+        if (valid[u]) x[u] = *reinterpret_cast<const u32x4 *>(a.in + idx);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t bu = b[u];
+      const bool raw = (B == 32) || (B < 0 && bu == 32);
+      u32x4 v = x[u];
+      if constexpr (MODE == MODE_D1) {
+        uint32_t prev = dpp0<DPP_WAVE_SHR1>(v.w);
+        if (k == 0) prev = seed[u];
+        v = u32x4{x[u].x - prev, x[u].y - x[u].x, x[u].z - x[u].y, x[u].w - x[u].z};
+      } else if constexpr (MODE == MODE_FOR) {
+        v -= seed[u];
+      }
+      if constexpr (MASKED) v &= field_mask(bu);
+
+      const uint32_t p = (uint32_t)k * bu, w = p >> 5, s = p & 31;
+      u32x4 acc = v << s;
+      // what this row hands to the next word
+      const bool spills = GENERIC ? (s + bu >= 32) : (s + bu > 32);
+      const uint32_t back = (32 - s) & 31;
+      u32x4 sp = spills ? (v >> back) : u32x4{0, 0, 0, 0};
+      u32x4 from_prev;
+      from_prev.x = dpp0<DPP_WAVE_SHR1>(sp.x);
+      from_prev.y = dpp0<DPP_WAVE_SHR1>(sp.y);
+      from_prev.z = dpp0<DPP_WAVE_SHR1>(sp.z);
+      from_prev.w = dpp0<DPP_WAVE_SHR1>(sp.w);
+      if (k == 0) {
+        from_prev = u32x4{0, 0, 0, 0};
+        if constexpr (GENERIC) {
+          if ((blk[u] > 0 || a.carry_first) && a.carry_blocks && bu > 0 && bu < 32) {
+            u32x4 c = carry[u];
+            if constexpr (MODE == MODE_FOR) c -= seed[u];
+            from_prev = c >> bu;
+          }
+        }
+      }
+      acc |= from_prev;
+
+      // OR together the threads whose rows start in the same word
+      const uint32_t w15 = (15u * bu) >> 5;
+#define SC_SEG_STEP(D, CTRL)                                                             \
+  if (B < 0 || D < max_rows_per_word(B)) {                                               \
+    const uint32_t same = ((((uint32_t)(k - D) * bu) >> 5) == w) ? 0xFFFFFFFFu : 0u;      \
+    acc.x |= dpp0<CTRL>(acc.x) & same;                                                   \
+    acc.y |= dpp0<CTRL>(acc.y) & same;                                                   \
+    acc.z |= dpp0<CTRL>(acc.z) & same;                                                   \
+    acc.w |= dpp0<CTRL>(acc.w) & same;                                                   \
+  }
+      SC_SEG_STEP(1, DPP_ROW_SHR1)
+      SC_SEG_STEP(2, DPP_ROW_SHR2)
+      SC_SEG_STEP(4, DPP_ROW_SHR4)
+      SC_SEG_STEP(8, DPP_ROW_SHR8)
+#undef SC_SEG_STEP
+      {
+        const uint32_t same = (k >= 16 && w15 == w) ? 0xFFFFFFFFu : 0u;
+        acc.x |= dpp0<DPP_ROW_BCAST15, 0xA>(acc.x) & same;
+        acc.y |= dpp0<DPP_ROW_BCAST15, 0xA>(acc.y) & same;
+        acc.z |= dpp0<DPP_ROW_BCAST15, 0xA>(acc.z) & same;
+        acc.w |= dpp0<DPP_ROW_BCAST15, 0xA>(acc.w) & same;
+      }
+      const bool last = (k == 31) || ((((uint32_t)(k + 1) * bu) >> 5) != w);
+      uint32_t nvec = bu;
+      if constexpr (GENERIC) {
+        const size_t start = blk[u] * 128;
+        const size_t nval = start < a.length ? (a.length - start < 128 ? a.length - start : 128) : 0;
+        nvec = (uint32_t)((((nval + 3) / 4) * bu + 31) / 32);
+      }
+      if (valid[u]) {
+        if (raw) {
+          if (!GENERIC) payload[vbase[u] + k] = x[u];
+        } else if (last && w < nvec) {
+          payload[vbase[u] + w] = acc;
+        }
+        if (MODE == MODE_D1 && a.seeds_out && k == 0) a.seeds_out[blk[u]] = seed[u];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// per-block reductions: maxbits / maxbitsd1 / min-max (+ frame width)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t bits_of(uint32_t v) { return v ? 32u - (uint32_t)__builtin_clz(v) : 0u; }
+
+template <int WHAT, int U>
+__global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int h = lane >> 5, k = lane & 31;
+  const size_t per_iter = (size_t)BLOCKS_PER_STEP * U;
+  const size_t ntiles = (a.nblocks + per_iter - 1) / per_iter;
+  for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const size_t first = tile * per_iter + (size_t)wv * 2 * U + h;
+    u32x4 x[U];
+    uint32_t seed[U];
+    bool valid[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t blk = first + 2 * (size_t)u;
+      valid[u] = blk < a.nblocks;
+      x[u] = u32x4{0, 0, 0, 0};
+      seed[u] = a.seed0;
+      if (valid[u]) {
+        x[u] = *reinterpret_cast<const u32x4 *>(a.in + blk * 128 + 4 * k);
+        if constexpr (WHAT == RED_MAXBITSD1) {
+          if (a.seeds) seed[u] = a.seeds[blk];
+          else if (blk > 0) seed[u] = a.in[blk * 128 - 1];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t blk = first + 2 * (size_t)u;
+      if constexpr (WHAT == RED_MINMAX) {
+        uint32_t lo = min(min(x[u].x, x[u].y), min(x[u].z, x[u].w));
+        uint32_t hi = max(max(x[u].x, x[u].y), max(x[u].z, x[u].w));
+        // butterfly over the 32 lanes of the half-wave
+#pragma unroll
+        for (int d = 1; d < 32; d <<= 1) {
+          lo = min(lo, (uint32_t)__shfl_xor((int)lo, d, 32));
+          hi = max(hi, (uint32_t)__shfl_xor((int)hi, d, 32));
+        }
+        if (valid[u] && k == 0) {
+          if (a.min_out) a.min_out[blk] = lo;
+          if (a.max_out) a.max_out[blk] = hi;
+          if (a.bits_out) a.bits_out[blk] = (uint8_t)bits_of(hi - lo);
+        }
+      } else {
+        u32x4 v = x[u];
+        if constexpr (WHAT == RED_MAXBITSD1) {
+          uint32_t prev = dpp0<DPP_WAVE_SHR1>(v.w);
+          if (k == 0) prev = seed[u];
+          v = u32x4{x[u].x - prev, x[u].y - x[u].x, x[u].z - x[u].y, x[u].w - x[u].z};
+        }
+        uint32_t t = v.x | v.y | v.z | v.w;
+        // OR-reduce into lane 31 of the half-wave
+        t |= dpp0<DPP_ROW_SHR1>(t);
+        t |= dpp0<DPP_ROW_SHR2>(t);
+        t |= dpp0<DPP_ROW_SHR4>(t);
+        t |= dpp0<DPP_ROW_SHR8>(t);
+        t |= dpp0<DPP_ROW_BCAST15, 0xA>(t);
+        if (valid[u] && k == 31) a.bits_out[blk] = (uint8_t)bits_of(t);
+        if (WHAT == RED_MAXBITSD1 && a.seeds_out && valid[u] && k == 0) a.seeds_out[blk] = seed[u];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// exclusive scan of 16 * bits[k] -> payload byte offsets (three small passes)
+// ---------------------------------------------------------------------------
+constexpr int SCAN_TILE = 4096;  // blocks per workgroup: 256 threads x 16
+
+__device__ __forceinline__ uint64_t block_reduce_sum(uint64_t v, uint64_t *sh) {
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor((unsigned long long)v, d, 64);
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) sh[wv] = v;
+  __syncthreads();
+  uint64_t tot = sh[0] + sh[1] + sh[2] + sh[3];
+  __syncthreads();
+  return tot;
+}
+
+__global__ __launch_bounds__(256) void k_scan_tile_sums(const uint8_t *bits, size_t n, uint64_t *tile_sums) {
+  __shared__ uint64_t sh[4];
+  const size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * 16;
+  uint64_t s = 0;
+  for (int i = 0; i < 16; ++i)
+    if (base + i < n) s += bits[base + i];
+  const uint64_t tot = block_reduce_sum(s, sh);
+  if (threadIdx.x == 0) tile_sums[blockIdx.x] = tot * 16;
+}
+
+// one workgroup: exclusive scan of the tile sums in place; total -> *total_out
+__global__ __launch_bounds__(256) void k_scan_spine(uint64_t *tile_sums, size_t ntiles, uint64_t *total_out) {
+  __shared__ uint64_t sh[256];
+  uint64_t carry = 0;
+  for (size_t base = 0; base < ntiles; base += 256) {
+    const size_t i = base + threadIdx.x;
+    const uint64_t v = i < ntiles ? tile_sums[i] : 0;
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+      const uint64_t t = threadIdx.x >= (unsigned)d ? sh[threadIdx.x - d] : 0;
+      __syncthreads();
+      sh[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if (i < ntiles) tile_sums[i] = carry + sh[threadIdx.x] - v;
+    carry += sh[255];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && total_out) *total_out = carry;
+}
+
+__global__ __launch_bounds__(256) void k_scan_apply(const uint8_t *bits, size_t n, const uint64_t *tile_sums,
+                                                    uint64_t *off) {
+  __shared__ uint64_t sh[256];
+  const size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * 16;
+  uint32_t loc[16];
+  uint64_t s = 0;
+  for (int i = 0; i < 16; ++i) {
+    loc[i] = base + i < n ? bits[base + i] : 0;
+    s += loc[i];
+  }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {
+    const uint64_t t = threadIdx.x >= (unsigned)d ? sh[threadIdx.x - d] : 0;
+    __syncthreads();
+    sh[threadIdx.x] += t;
+    __syncthreads();
+  }
+  uint64_t run = tile_sums[blockIdx.x] + (sh[threadIdx.x] - s) * 16;
+  for (int i = 0; i < 16; ++i) {
+    if (base + i < n) off[base + i] = run;
+    run += (uint64_t)loc[i] * 16;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// verification helpers: position-sensitive 64-bit checksum and mismatch count
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+// acc[0] += sum over words i of mix64((index0 + i) << 32 | word[i]); when `other`
+// is given, acc[1] += number of words that differ from other[i].
+__global__ __launch_bounds__(256) void k_checksum(const uint32_t *data, const uint32_t *other, size_t nwords,
+                                                  uint64_t index0, unsigned long long *acc) {
+  __shared__ uint64_t sh[4];
+  uint64_t s = 0, bad = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nwords; i += (size_t)gridDim.x * 256) {
+    const uint32_t v = data[i];
+    s += mix64(((index0 + i) << 32) ^ v);
+    if (other) bad += (other[i] != v);
+  }
+  const uint64_t tot = block_reduce_sum(s, sh);
+  const uint64_t totbad = block_reduce_sum(bad, sh);
+  if (threadIdx.x == 0) {
+    atomicAdd(&acc[0], (unsigned long long)tot);
+    if (other && totbad) atomicAdd(&acc[1], (unsigned long long)totbad);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// whole-array reductions for the *_length routines: r[0] = OR of the values,
+// r[1] = OR of successive differences seeded by `init`, r[2] = min, r[3] = max
+// ---------------------------------------------------------------------------
+__global__ void k_reduce_array_init(uint32_t *r) {
+  r[0] = 0;
+  r[1] = 0;
+  r[2] = 0xFFFFFFFFu;
+  r[3] = 0;
+}
+
+__global__ __launch_bounds__(256) void k_reduce_array(const uint32_t *in, size_t n, uint32_t init, uint32_t *r) {
+  uint32_t o = 0, od = 0, lo = 0xFFFFFFFFu, hi = 0;
+  const size_t stride = (size_t)gridDim.x * 256, gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const bool vec = (reinterpret_cast<uintptr_t>(in) & 15u) == 0;
+  const size_t nvec = vec ? n / 4 : 0;
+  const u32x4 *in4 = reinterpret_cast<const u32x4 *>(in);
+  for (size_t j = gid; j < nvec; j += stride) {
+    const u32x4 v = in4[j];
+    const uint32_t prev = j ? in[4 * j - 1] : init;
+    o |= v.x | v.y | v.z | v.w;
+    od |= (v.x - prev) | (v.y - v.x) | (v.z - v.y) | (v.w - v.z);
+    lo = min(lo, min(min(v.x, v.y), min(v.z, v.w)));
+    hi = max(hi, max(max(v.x, v.y), max(v.z, v.w)));
+  }
+  for (size_t i = 4 * nvec + gid; i < n; i += stride) {
+    const uint32_t v = in[i], prev = i ? in[i - 1] : init;
+    o |= v;
+    od |= v - prev;
+    lo = min(lo, v);
+    hi = max(hi, v);
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    o |= (uint32_t)__shfl_xor((int)o, d, 64);
+    od |= (uint32_t)__shfl_xor((int)od, d, 64);
+    lo = min(lo, (uint32_t)__shfl_xor((int)lo, d, 64));
+    hi = max(hi, (uint32_t)__shfl_xor((int)hi, d, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (o) atomicOr(&r[0], o);
+    if (od) atomicOr(&r[1], od);
+    atomicMin(&r[2], lo);
+    atomicMax(&r[3], hi);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+static int grid_for(size_t nblocks, int U) {
+  const size_t per_iter = (size_t)BLOCKS_PER_STEP * U;
+  size_t tiles = (nblocks + per_iter - 1) / per_iter;
+  const size_t cap = 256 * 8;  // 256 CUs x 8 resident workgroups
+  if (tiles > cap) tiles = cap;
+  if (tiles < 1) tiles = 1;
+  return (int)tiles;
+}
+
+constexpr int UNPACK_U = 4;
+constexpr int PACK_U = 4;
+constexpr int REDUCE_U = 4;
+
+template <int MODE, int B>
+static void launch_unpack_fixed(const UnpackArgs &a, hipStream_t st) {
+  hipLaunchKernelGGL((k_unpack<B, MODE, UNPACK_U, false>), dim3(grid_for(a.nblocks, UNPACK_U)), dim3(256), 0, st, a);
+}
+
+template <int MODE, int... Bs>
+static void dispatch_unpack(const UnpackArgs &a, hipStream_t st, std::integer_sequence<int, Bs...>) {
+  using fn_t = void (*)(const UnpackArgs &, hipStream_t);
+  static const fn_t table[] = {&launch_unpack_fixed<MODE, Bs>...};
+  table[a.bit](a, st);
+}
+
+hipError_t launch_unpack(int mode, bool runtime_width, bool tail, const UnpackArgs &a, hipStream_t st) {
+  if (a.nblocks == 0) return hipSuccess;
+  if (runtime_width || tail) {
+    const dim3 g(grid_for(a.nblocks, UNPACK_U)), t(256);
+#define SC_RT(MODE_)                                                                         \
+  if (tail) hipLaunchKernelGGL((k_unpack<-1, MODE_, UNPACK_U, true>), g, t, 0, st, a);        \
+  else hipLaunchKernelGGL((k_unpack<-1, MODE_, UNPACK_U, false>), g, t, 0, st, a);
+    if (mode == MODE_PLAIN) { SC_RT(MODE_PLAIN) }
+    else if (mode == MODE_D1) { SC_RT(MODE_D1) }
+    else { SC_RT(MODE_FOR) }
+#undef SC_RT
+  } else {
+    using seq = std::make_integer_sequence<int, 33>;
+    if (mode == MODE_PLAIN) dispatch_unpack<MODE_PLAIN>(a, st, seq{});
+    else if (mode == MODE_D1) dispatch_unpack<MODE_D1>(a, st, seq{});
+    else dispatch_unpack<MODE_FOR>(a, st, seq{});
+  }
+  return hipGetLastError();
+}
+
+template <int MODE, bool MASKED, int B>
+static void launch_pack_fixed(const PackArgs &a, hipStream_t st) {
+  hipLaunchKernelGGL((k_pack<B, MODE, MASKED, PACK_U, false>), dim3(grid_for(a.nblocks, PACK_U)), dim3(256), 0, st, a);
+}
+
+template <int MODE, bool MASKED, int... Bs>
+static void dispatch_pack(const PackArgs &a, hipStream_t st, std::integer_sequence<int, Bs...>) {
+  using fn_t = void (*)(const PackArgs &, hipStream_t);
+  static const fn_t table[] = {&launch_pack_fixed<MODE, MASKED, Bs>...};
+  table[a.bit](a, st);
+}
+
+hipError_t launch_pack(int mode, bool masked, bool runtime_width, bool generic, const PackArgs &a, hipStream_t st) {
+  if (a.nblocks == 0) return hipSuccess;
+  const dim3 g(grid_for(a.nblocks, PACK_U)), t(256);
+  using seq = std::make_integer_sequence<int, 33>;
+  if (generic) {
+    // arbitrary-length packer: unmasked by definition (plain or frame-of-reference)
+    if (mode == MODE_FOR) hipLaunchKernelGGL((k_pack<-1, MODE_FOR, false, PACK_U, true>), g, t, 0, st, a);
+    else hipLaunchKernelGGL((k_pack<-1, MODE_PLAIN, false, PACK_U, true>), g, t, 0, st, a);
+  } else if (runtime_width) {
+#define SC_RT(MODE_)                                                                           \
+  if (masked) hipLaunchKernelGGL((k_pack<-1, MODE_, true, PACK_U, false>), g, t, 0, st, a);     \
+  else hipLaunchKernelGGL((k_pack<-1, MODE_, false, PACK_U, false>), g, t, 0, st, a);
+    if (mode == MODE_PLAIN) { SC_RT(MODE_PLAIN) }
+    else if (mode == MODE_D1) { SC_RT(MODE_D1) }
+    else { SC_RT(MODE_FOR) }
+#undef SC_RT
+  } else {
+    if (mode == MODE_PLAIN) {
+      if (masked) dispatch_pack<MODE_PLAIN, true>(a, st, seq{});
+      else dispatch_pack<MODE_PLAIN, false>(a, st, seq{});
+    } else if (mode == MODE_D1) {
+      if (masked) dispatch_pack<MODE_D1, true>(a, st, seq{});
+      else dispatch_pack<MODE_D1, false>(a, st, seq{});
+    } else {
+      dispatch_pack<MODE_FOR, false>(a, st, seq{});
+    }
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_reduce(int what, const ReduceArgs &a, hipStream_t st) {
+  if (a.nblocks == 0) return hipSuccess;
+  const dim3 g(grid_for(a.nblocks, REDUCE_U)), t(256);
+  if (what == RED_MAXBITS) hipLaunchKernelGGL((k_reduce<RED_MAXBITS, REDUCE_U>), g, t, 0, st, a);
+  else if (what == RED_MAXBITSD1) hipLaunchKernelGGL((k_reduce<RED_MAXBITSD1, REDUCE_U>), g, t, 0, st, a);
+  else hipLaunchKernelGGL((k_reduce<RED_MINMAX, REDUCE_U>), g, t, 0, st, a);
+  return hipGetLastError();
+}
+
+size_t scan_workspace_bytes(size_t nblocks) {
+  const size_t ntiles = (nblocks + SCAN_TILE - 1) / SCAN_TILE;
+  return (ntiles ? ntiles : 1) * sizeof(uint64_t);
+}
+
+hipError_t launch_payload_offsets(const uint8_t *bits, size_t nblocks, uint64_t *off, uint64_t *total,
+                                  void *workspace, hipStream_t st) {
+  uint64_t *tile_sums = reinterpret_cast<uint64_t *>(workspace);
+  const size_t ntiles = (nblocks + SCAN_TILE - 1) / SCAN_TILE;
+  if (nblocks == 0) {
+    if (total) return hipMemsetAsync(total, 0, sizeof(uint64_t), st);
+    return hipSuccess;
+  }
+  hipLaunchKernelGGL(k_scan_tile_sums, dim3((unsigned)ntiles), dim3(256), 0, st, bits, nblocks, tile_sums);
+  hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(256), 0, st, tile_sums, ntiles, total);
+  hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)ntiles), dim3(256), 0, st, bits, nblocks, tile_sums, off);
+  return hipGetLastError();
+}
+
+hipError_t launch_checksum(const uint32_t *data, const uint32_t *other, size_t nwords, uint64_t index0,
+                           uint64_t *acc, hipStream_t st) {
+  if (nwords == 0) return hipSuccess;
+  size_t g = (nwords + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(k_checksum, dim3((unsigned)g), dim3(256), 0, st, data, other, nwords, index0,
+                     reinterpret_cast<unsigned long long *>(acc));
+  return hipGetLastError();
+}
+
+hipError_t launch_reduce_array(const uint32_t *in, size_t length, uint32_t init, uint32_t *result4, hipStream_t st) {
+  hipLaunchKernelGGL(k_reduce_array_init, dim3(1), dim3(1), 0, st, result4);
+  if (length) {
+    size_t g = (length / 4 + 255) / 256;
+    if (g > 2048) g = 2048;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(k_reduce_array, dim3((unsigned)g), dim3(256), 0, st, in, length, init, result4);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace sc

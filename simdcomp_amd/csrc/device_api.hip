@@ -1,0 +1,316 @@
+// extern "C" batched device-pointer entry points declared in include/simdcomp_hip.h:
+// argument checks, then a kernel launch on the caller's stream.  Nothing here
+// allocates, frees or synchronises.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/simdcomp_hip.h"
+#include "codec_kernels.h"
+
+namespace {
+
+thread_local char g_err[256] = "";
+
+int fail(int code, const char *what) {
+  snprintf(g_err, sizeof g_err, "%s", what);
+  return code;
+}
+
+int hip_result(hipError_t e, const char *where) {
+  if (e == hipSuccess) return SIMDCOMP_HIP_OK;
+  snprintf(g_err, sizeof g_err, "%s: %s", where, hipGetErrorString(e));
+  return (int)e;
+}
+
+bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+int check_common(const void *ints, const void *payload, size_t nblocks, uint32_t bit, bool need_payload) {
+  if (bit > 32) return fail(SIMDCOMP_HIP_EBIT, "bit width > 32");
+  if (nblocks == 0) return SIMDCOMP_HIP_OK;
+  if (!ints) return fail(SIMDCOMP_HIP_ENULL, "integer array is NULL");
+  if (need_payload && !payload) return fail(SIMDCOMP_HIP_ENULL, "payload pointer is NULL");
+  if (!aligned16(ints) || !aligned16(payload)) return fail(SIMDCOMP_HIP_EALIGN, "pointer not 16-byte aligned");
+  return SIMDCOMP_HIP_OK;
+}
+
+int do_pack(int mode, int masked, uint32_t initvalue, const uint32_t *seeds, const uint32_t *in, void *payload,
+            const uint64_t *off, const uint8_t *bits, uint32_t bit, size_t nblocks, uint32_t *seeds_out,
+            void *stream) {
+  const bool mixed = bits != nullptr;
+  if (int rc = check_common(in, payload, nblocks, mixed ? 0 : bit, mixed || bit != 0)) return rc;
+  if (mixed && !off && nblocks) return fail(SIMDCOMP_HIP_ENULL, "per-block widths need per-block payload offsets");
+  if (mode == SIMDCOMP_HIP_FOR && !seeds && mixed && nblocks)
+    return fail(SIMDCOMP_HIP_ENULL, "frame bases are NULL");
+  sc::PackArgs a{};
+  a.in = in;
+  a.payload = payload;
+  a.off = off;
+  a.bits = bits;
+  a.seeds = seeds;
+  a.seeds_out = seeds_out;
+  a.nblocks = nblocks;
+  a.length = nblocks * 128;
+  a.bit = bit;
+  a.seed0 = initvalue;
+  a.carry_blocks = 0;
+  return hip_result(sc::launch_pack(mode, masked != 0 && mode != SIMDCOMP_HIP_FOR, mixed || off != nullptr, false, a,
+                                    as_stream(stream)),
+                    "pack launch");
+}
+
+int do_unpack(int mode, uint32_t seed0, const uint32_t *seeds, const void *payload, const uint64_t *off,
+              const uint8_t *bits, uint32_t bit, uint32_t *out, size_t nblocks, void *stream) {
+  const bool mixed = bits != nullptr;
+  if (int rc = check_common(out, payload, nblocks, mixed ? 0 : bit, mixed || bit != 0)) return rc;
+  if (mixed && !off && nblocks) return fail(SIMDCOMP_HIP_ENULL, "per-block widths need per-block payload offsets");
+  sc::UnpackArgs a{};
+  a.payload = payload;
+  a.off = off;
+  a.bits = bits;
+  a.seeds = seeds;
+  a.out = out;
+  a.nblocks = nblocks;
+  a.length = nblocks * 128;
+  a.bit = bit;
+  a.seed0 = seed0;
+  return hip_result(sc::launch_unpack(mode, mixed || off != nullptr, false, a, as_stream(stream)), "unpack launch");
+}
+
+}  // namespace
+
+extern "C" {
+
+int simdcomp_hip_version(void) { return 100; }
+
+const char *simdcomp_hip_last_error(void) { return g_err; }
+
+int simdcomp_hip_pack(const uint32_t *d_in, void *d_out, size_t nblocks, uint32_t bit, int masked, void *stream) {
+  return do_pack(sc::MODE_PLAIN, masked, 0, nullptr, d_in, d_out, nullptr, nullptr, bit, nblocks, nullptr, stream);
+}
+
+int simdcomp_hip_unpack(const void *d_in, uint32_t *d_out, size_t nblocks, uint32_t bit, void *stream) {
+  return do_unpack(sc::MODE_PLAIN, 0, nullptr, d_in, nullptr, nullptr, bit, d_out, nblocks, stream);
+}
+
+int simdcomp_hip_packd1(uint32_t initvalue, const uint32_t *d_initvalues, const uint32_t *d_in, void *d_out,
+                        size_t nblocks, uint32_t bit, int masked, uint32_t *d_initvalues_out, void *stream) {
+  return do_pack(sc::MODE_D1, masked, initvalue, d_initvalues, d_in, d_out, nullptr, nullptr, bit, nblocks,
+                 d_initvalues_out, stream);
+}
+
+int simdcomp_hip_unpackd1(const uint32_t *d_initvalues, const void *d_in, uint32_t *d_out, size_t nblocks,
+                          uint32_t bit, void *stream) {
+  if (!d_initvalues && nblocks) return fail(SIMDCOMP_HIP_ENULL, "d_initvalues is NULL");
+  return do_unpack(sc::MODE_D1, 0, d_initvalues, d_in, nullptr, nullptr, bit, d_out, nblocks, stream);
+}
+
+int simdcomp_hip_packFOR(const uint32_t *d_initvalues, const uint32_t *d_in, void *d_out, size_t nblocks,
+                         uint32_t bit, void *stream) {
+  if (!d_initvalues && nblocks) return fail(SIMDCOMP_HIP_ENULL, "d_initvalues is NULL");
+  return do_pack(sc::MODE_FOR, 0, 0, d_initvalues, d_in, d_out, nullptr, nullptr, bit, nblocks, nullptr, stream);
+}
+
+int simdcomp_hip_unpackFOR(const uint32_t *d_initvalues, const void *d_in, uint32_t *d_out, size_t nblocks,
+                           uint32_t bit, void *stream) {
+  if (!d_initvalues && nblocks) return fail(SIMDCOMP_HIP_ENULL, "d_initvalues is NULL");
+  return do_unpack(sc::MODE_FOR, 0, d_initvalues, d_in, nullptr, nullptr, bit, d_out, nblocks, stream);
+}
+
+int simdcomp_hip_pack_mixed(int mode, int masked, uint32_t initvalue, const uint32_t *d_initvalues,
+                            const uint32_t *d_in, void *d_payload, const uint64_t *d_payload_offsets,
+                            const uint8_t *d_bits, size_t nblocks, uint32_t *d_initvalues_out, void *stream) {
+  if (mode < 0 || mode > 2) return fail(SIMDCOMP_HIP_EMODE, "unknown mode");
+  if (!d_bits && nblocks) return fail(SIMDCOMP_HIP_ENULL, "d_bits is NULL");
+  return do_pack(mode, masked, initvalue, d_initvalues, d_in, d_payload, d_payload_offsets, d_bits, 0, nblocks,
+                 d_initvalues_out, stream);
+}
+
+int simdcomp_hip_unpack_mixed(int mode, const uint32_t *d_initvalues, const void *d_payload,
+                              const uint64_t *d_payload_offsets, const uint8_t *d_bits, uint32_t *d_out,
+                              size_t nblocks, void *stream) {
+  if (mode < 0 || mode > 2) return fail(SIMDCOMP_HIP_EMODE, "unknown mode");
+  if (!d_bits && nblocks) return fail(SIMDCOMP_HIP_ENULL, "d_bits is NULL");
+  if (mode != SIMDCOMP_HIP_PLAIN && !d_initvalues && nblocks) return fail(SIMDCOMP_HIP_ENULL, "d_initvalues is NULL");
+  return do_unpack(mode, 0, d_initvalues, d_payload, d_payload_offsets, d_bits, 0, d_out, nblocks, stream);
+}
+
+int simdcomp_hip_maxbits(const uint32_t *d_in, size_t nblocks, uint8_t *d_bits, void *stream) {
+  if (nblocks == 0) return SIMDCOMP_HIP_OK;
+  if (!d_in || !d_bits) return fail(SIMDCOMP_HIP_ENULL, "NULL pointer");
+  if (!aligned16(d_in)) return fail(SIMDCOMP_HIP_EALIGN, "pointer not 16-byte aligned");
+  sc::ReduceArgs a{};
+  a.in = d_in;
+  a.bits_out = d_bits;
+  a.nblocks = nblocks;
+  return hip_result(sc::launch_reduce(sc::RED_MAXBITS, a, as_stream(stream)), "maxbits launch");
+}
+
+int simdcomp_hip_maxbitsd1(uint32_t initvalue, const uint32_t *d_initvalues, const uint32_t *d_in, size_t nblocks,
+                           uint8_t *d_bits, uint32_t *d_initvalues_out, void *stream) {
+  if (nblocks == 0) return SIMDCOMP_HIP_OK;
+  if (!d_in || !d_bits) return fail(SIMDCOMP_HIP_ENULL, "NULL pointer");
+  if (!aligned16(d_in)) return fail(SIMDCOMP_HIP_EALIGN, "pointer not 16-byte aligned");
+  sc::ReduceArgs a{};
+  a.in = d_in;
+  a.seeds = d_initvalues;
+  a.seeds_out = d_initvalues_out;
+  a.bits_out = d_bits;
+  a.nblocks = nblocks;
+  a.seed0 = initvalue;
+  return hip_result(sc::launch_reduce(sc::RED_MAXBITSD1, a, as_stream(stream)), "maxbitsd1 launch");
+}
+
+int simdcomp_hip_maxmin(const uint32_t *d_in, size_t nblocks, uint32_t *d_min, uint32_t *d_max, uint8_t *d_bits,
+                        void *stream) {
+  if (nblocks == 0) return SIMDCOMP_HIP_OK;
+  if (!d_in) return fail(SIMDCOMP_HIP_ENULL, "NULL pointer");
+  if (!aligned16(d_in)) return fail(SIMDCOMP_HIP_EALIGN, "pointer not 16-byte aligned");
+  sc::ReduceArgs a{};
+  a.in = d_in;
+  a.min_out = d_min;
+  a.max_out = d_max;
+  a.bits_out = d_bits;
+  a.nblocks = nblocks;
+  return hip_result(sc::launch_reduce(sc::RED_MINMAX, a, as_stream(stream)), "maxmin launch");
+}
+
+int simdcomp_hip_reduce_length(const uint32_t *d_in, size_t length, uint32_t initvalue, uint32_t *d_result4,
+                               void *stream) {
+  if (!d_result4 || (!d_in && length)) return fail(SIMDCOMP_HIP_ENULL, "NULL pointer");
+  return hip_result(sc::launch_reduce_array(d_in, length, initvalue, d_result4, as_stream(stream)), "reduce launch");
+}
+
+size_t simdcomp_hip_payload_offsets_workspace(size_t nblocks) { return sc::scan_workspace_bytes(nblocks); }
+
+int simdcomp_hip_payload_offsets(const uint8_t *d_bits, size_t nblocks, uint64_t *d_payload_offsets,
+                                 uint64_t *d_total_bytes, void *d_workspace, void *stream) {
+  if (nblocks && (!d_bits || !d_payload_offsets || !d_workspace)) return fail(SIMDCOMP_HIP_ENULL, "NULL pointer");
+  return hip_result(sc::launch_payload_offsets(d_bits, nblocks, d_payload_offsets, d_total_bytes, d_workspace,
+                                               as_stream(stream)),
+                    "payload offsets launch");
+}
+
+size_t simdcomp_hip_compressedbytes(size_t length, uint32_t bit) {
+  if (bit == 0) return 0;
+  if (bit >= 32) return length * 4;
+  return (((length + 3) / 4) * (size_t)bit + 31) / 32 * 16;
+}
+
+int simdcomp_hip_pack_length(const uint32_t *d_in, size_t length, void *d_out, uint32_t bit, void *stream) {
+  if (bit > 32) return fail(SIMDCOMP_HIP_EBIT, "bit width > 32");
+  if (length == 0 || bit == 0) return SIMDCOMP_HIP_OK;
+  if (!d_in || !d_out) return fail(SIMDCOMP_HIP_ENULL, "NULL pointer");
+  if (bit == 32)
+    return hip_result(hipMemcpyAsync(d_out, d_in, length * 4, hipMemcpyDeviceToDevice, as_stream(stream)), "copy");
+  const size_t nfull = length / 128, rest = length % 128;
+  if (int rc = simdcomp_hip_pack(d_in, d_out, nfull, bit, 1, stream)) return rc;
+  if (rest) {
+    if (!aligned16(d_in) || !aligned16(d_out)) return fail(SIMDCOMP_HIP_EALIGN, "pointer not 16-byte aligned");
+    sc::PackArgs a{};
+    a.in = d_in + nfull * 128;
+    a.payload = static_cast<uint8_t *>(d_out) + nfull * 16 * bit;
+    a.nblocks = 1;
+    a.length = rest;
+    a.bit = bit;
+    return hip_result(sc::launch_pack(sc::MODE_PLAIN, false, true, true, a, as_stream(stream)), "pack tail launch");
+  }
+  return SIMDCOMP_HIP_OK;
+}
+
+static int unpack_length_common(int mode, uint32_t initvalue, const void *d_in, size_t length, uint32_t *d_out,
+                                uint32_t bit, void *stream) {
+  if (bit > 32) return fail(SIMDCOMP_HIP_EBIT, "bit width > 32");
+  if (length == 0) return SIMDCOMP_HIP_OK;
+  if (!d_out || (!d_in && bit)) return fail(SIMDCOMP_HIP_ENULL, "NULL pointer");
+  if (bit == 32)
+    return hip_result(hipMemcpyAsync(d_out, d_in, length * 4, hipMemcpyDeviceToDevice, as_stream(stream)), "copy");
+  if (!aligned16(d_in) || !aligned16(d_out)) return fail(SIMDCOMP_HIP_EALIGN, "pointer not 16-byte aligned");
+  const size_t nfull = length / 128, rest = length % 128;
+  if (int rc = do_unpack(mode, initvalue, nullptr, d_in, nullptr, nullptr, bit, d_out, nfull, stream)) return rc;
+  if (rest) {
+    sc::UnpackArgs a{};
+    a.payload = static_cast<const uint8_t *>(d_in) + nfull * 16 * bit;
+    a.out = d_out + nfull * 128;
+    a.nblocks = 1;
+    a.length = rest;
+    a.bit = bit;
+    a.seed0 = initvalue;
+    return hip_result(sc::launch_unpack(mode, true, true, a, as_stream(stream)), "unpack tail launch");
+  }
+  return SIMDCOMP_HIP_OK;
+}
+
+int simdcomp_hip_unpack_length(const void *d_in, size_t length, uint32_t *d_out, uint32_t bit, void *stream) {
+  return unpack_length_common(sc::MODE_PLAIN, 0, d_in, length, d_out, bit, stream);
+}
+
+int simdcomp_hip_packFOR_length(uint32_t initvalue, const uint32_t *d_in, size_t length, void *d_out, uint32_t bit,
+                                int carry_in, void *stream) {
+  if (bit > 32) return fail(SIMDCOMP_HIP_EBIT, "bit width > 32");
+  if (length == 0 || bit == 0) return SIMDCOMP_HIP_OK;
+  if (!d_in || !d_out) return fail(SIMDCOMP_HIP_ENULL, "NULL pointer");
+  if (bit == 32)
+    return hip_result(hipMemcpyAsync(d_out, d_in, length * 4, hipMemcpyDeviceToDevice, as_stream(stream)), "copy");
+  if (!aligned16(d_in) || !aligned16(d_out)) return fail(SIMDCOMP_HIP_EALIGN, "pointer not 16-byte aligned");
+  sc::PackArgs a{};
+  a.in = d_in;
+  a.payload = d_out;
+  a.nblocks = (length + 127) / 128;
+  a.length = length;
+  a.bit = bit;
+  a.seed0 = initvalue;
+  a.carry_blocks = 1;
+  a.carry_first = carry_in != 0;
+  return hip_result(sc::launch_pack(sc::MODE_FOR, false, true, true, a, as_stream(stream)), "packFOR_length launch");
+}
+
+int simdcomp_hip_unpackFOR_length(uint32_t initvalue, const void *d_in, size_t length, uint32_t *d_out,
+                                  uint32_t bit, void *stream) {
+  return unpack_length_common(sc::MODE_FOR, initvalue, d_in, length, d_out, bit, stream);
+}
+
+int simdcomp_hip_partition(size_t nblocks, int nparts, int part, size_t *first, size_t *count) {
+  if (nparts <= 0 || part < 0 || part >= nparts || !first || !count) return fail(SIMDCOMP_HIP_ESIZE, "bad partition");
+  const size_t lo = (size_t)((unsigned __int128)nblocks * (unsigned)part / (unsigned)nparts);
+  const size_t hi = (size_t)((unsigned __int128)nblocks * (unsigned)(part + 1) / (unsigned)nparts);
+  *first = lo;
+  *count = hi - lo;
+  return SIMDCOMP_HIP_OK;
+}
+
+int simdcomp_hip_partition_by_bytes(const uint64_t *h_payload_offsets, size_t nblocks, int nparts, int part,
+                                    size_t *first, size_t *count) {
+  if (nparts <= 0 || part < 0 || part >= nparts || !first || !count || (!h_payload_offsets && nblocks))
+    return fail(SIMDCOMP_HIP_ESIZE, "bad partition");
+  // cost of blocks [0, k): payload bytes read + 512 bytes written per block
+  auto cost = [&](size_t k) -> unsigned __int128 {
+    return (unsigned __int128)(h_payload_offsets[k] - h_payload_offsets[0]) + (unsigned __int128)k * 512u;
+  };
+  auto cut = [&](int p) -> size_t {
+    if (p <= 0) return 0;
+    if (p >= nparts) return nblocks;
+    const unsigned __int128 target = cost(nblocks) * (unsigned)p / (unsigned)nparts;
+    size_t lo = 0, hi = nblocks;  // first k with cost(k) >= target
+    while (lo < hi) {
+      const size_t mid = lo + (hi - lo) / 2;
+      if (cost(mid) < target) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+  };
+  const size_t a = nblocks ? cut(part) : 0, b = nblocks ? cut(part + 1) : 0;
+  *first = a;
+  *count = b - a;
+  return SIMDCOMP_HIP_OK;
+}
+
+int simdcomp_hip_checksum(const uint32_t *d_data, const uint32_t *d_other, size_t nwords, uint64_t index0,
+                          uint64_t *d_acc, void *stream) {
+  if (nwords == 0) return SIMDCOMP_HIP_OK;
+  if (!d_data || !d_acc) return fail(SIMDCOMP_HIP_ENULL, "NULL pointer");
+  return hip_result(sc::launch_checksum(d_data, d_other, nwords, index0, d_acc, as_stream(stream)), "checksum launch");
+}
+
+}  // extern "C"

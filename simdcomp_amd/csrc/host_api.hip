@@ -1,0 +1,325 @@
+// Reference-signature entry points (include/simdcomp.h): HOST pointers in and
+// out, the work done by the HIP kernels.  Operands are staged into device
+// buffers owned by this file, the same kernels the batched device entry points
+// use are launched on an internal stream, and results are copied back before
+// the call returns.  There is no CPU implementation behind these routines:
+// without a working GPU they print the HIP error and abort.
+//
+// Long arrays (*_length) are moved in pieces of PIECE integers over two
+// streams with two sets of staging buffers, so that with pinned caller memory
+// the upload of one piece overlaps the kernel and the download of the previous
+// one.  Pageable caller memory works too (the HIP runtime stages it).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <mutex>
+
+#include "../../include/simdcomp.h"
+#include "../../include/simdcomp_hip.h"
+#include "codec_kernels.h"
+
+namespace {
+
+constexpr size_t PIECE = (size_t)1 << 24;  // integers per pipeline piece (64 MiB), a multiple of 128
+
+[[noreturn]] void die(const char *where, const char *what) {
+  fprintf(stderr, "simdcomp_hip: %s failed: %s\n", where, what);
+  abort();
+}
+
+void ck(hipError_t e, const char *where) {
+  if (e != hipSuccess) die(where, hipGetErrorString(e));
+}
+
+void ckapi(int rc, const char *where) {
+  if (rc != 0) die(where, simdcomp_hip_last_error());
+}
+
+struct Staging {
+  std::mutex mu;
+  bool ready = false;
+  hipStream_t stream[2] = {nullptr, nullptr};
+  void *in[2] = {nullptr, nullptr};
+  void *out[2] = {nullptr, nullptr};
+  size_t in_cap[2] = {0, 0}, out_cap[2] = {0, 0};
+  uint32_t *result4 = nullptr;  // device scratch for whole-array reductions
+
+  void init() {
+    if (ready) return;
+    int n = 0;
+    ck(hipGetDeviceCount(&n), "hipGetDeviceCount");
+    if (n <= 0) die("device discovery", "no HIP device");
+    for (int i = 0; i < 2; ++i) ck(hipStreamCreateWithFlags(&stream[i], hipStreamNonBlocking), "hipStreamCreate");
+    ck(hipMalloc(reinterpret_cast<void **>(&result4), 64), "hipMalloc");
+    ready = true;
+  }
+
+  void reserve(int slot, size_t in_bytes, size_t out_bytes) {
+    init();
+    in_bytes += 64;  // 16 bytes in front of din() hold the previous row of a piecewise FOR pack
+    out_bytes += 64;
+    if (in_bytes > in_cap[slot]) {
+      ck(hipStreamSynchronize(stream[slot]), "hipStreamSynchronize");
+      if (in[slot]) ck(hipFree(in[slot]), "hipFree");
+      ck(hipMalloc(&in[slot], in_bytes), "hipMalloc");
+      in_cap[slot] = in_bytes;
+    }
+    if (out_bytes > out_cap[slot]) {
+      ck(hipStreamSynchronize(stream[slot]), "hipStreamSynchronize");
+      if (out[slot]) ck(hipFree(out[slot]), "hipFree");
+      ck(hipMalloc(&out[slot], out_bytes), "hipMalloc");
+      out_cap[slot] = out_bytes;
+    }
+  }
+  uint8_t *din(int slot) { return static_cast<uint8_t *>(in[slot]) + 16; }
+  uint8_t *dout(int slot) { return static_cast<uint8_t *>(out[slot]); }
+};
+
+Staging &staging() {
+  static Staging s;
+  return s;
+}
+
+void h2d(void *dst, const void *src, size_t n, hipStream_t st) {
+  if (n) ck(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, st), "hipMemcpyAsync H2D");
+}
+void d2h(void *dst, const void *src, size_t n, hipStream_t st) {
+  if (n) ck(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, st), "hipMemcpyAsync D2H");
+}
+
+// ---- one 128-integer block ---------------------------------------------------
+
+void block_pack(int mode, bool masked, uint32_t initvalue, const uint32_t *in, void *out, uint32_t bit) {
+  if (bit > 32) return;  // the reference's switch falls through and does nothing
+  Staging &s = staging();
+  std::lock_guard<std::mutex> lock(s.mu);
+  s.reserve(0, 512, 512);
+  hipStream_t st = s.stream[0];
+  h2d(s.din(0), in, 512, st);
+  sc::PackArgs a{};
+  a.in = reinterpret_cast<const uint32_t *>(s.din(0));
+  a.payload = s.dout(0);
+  a.nblocks = 1;
+  a.length = 128;
+  a.bit = bit;
+  a.seed0 = initvalue;  // seeds == nullptr: block 0 of a chained d1 stream / uniform frame base
+  ck(sc::launch_pack(mode, masked, false, false, a, st), "pack launch");
+  d2h(out, s.dout(0), 16 * (size_t)bit, st);
+  ck(hipStreamSynchronize(st), "hipStreamSynchronize");
+}
+
+void block_unpack(int mode, uint32_t initvalue, const void *in, uint32_t *out, uint32_t bit) {
+  if (bit > 32) return;
+  Staging &s = staging();
+  std::lock_guard<std::mutex> lock(s.mu);
+  s.reserve(0, 512, 512);
+  hipStream_t st = s.stream[0];
+  h2d(s.din(0), in, 16 * (size_t)bit, st);
+  sc::UnpackArgs a{};
+  a.payload = s.din(0);
+  a.out = reinterpret_cast<uint32_t *>(s.dout(0));
+  a.nblocks = 1;
+  a.length = 128;
+  a.bit = bit;
+  a.seed0 = initvalue;
+  ck(sc::launch_unpack(mode, false, false, a, st), "unpack launch");
+  d2h(out, s.dout(0), 512, st);
+  ck(hipStreamSynchronize(st), "hipStreamSynchronize");
+}
+
+// ---- whole-array reductions ----------------------------------------------------
+
+void reduce_host(const uint32_t *in, size_t length, uint32_t initvalue, uint32_t r[4]) {
+  uint32_t acc[4] = {0, 0, 0xFFFFFFFFu, 0};  // what an empty range yields (src/simdcomputil.c:135-136)
+  uint32_t prev = initvalue;
+  if (length) {
+    Staging &s = staging();
+    std::lock_guard<std::mutex> lock(s.mu);
+    s.init();
+    hipStream_t st = s.stream[0];
+    for (size_t done = 0; done < length; done += PIECE) {
+      const size_t n = length - done < PIECE ? length - done : PIECE;
+      s.reserve(0, n * 4, 0);
+      h2d(s.din(0), in + done, n * 4, st);
+      ckapi(simdcomp_hip_reduce_length(reinterpret_cast<const uint32_t *>(s.din(0)), n, prev, s.result4, st),
+            "reduce");
+      uint32_t part[4];
+      d2h(part, s.result4, 16, st);
+      ck(hipStreamSynchronize(st), "hipStreamSynchronize");
+      acc[0] |= part[0];
+      acc[1] |= part[1];
+      if (part[2] < acc[2]) acc[2] = part[2];
+      if (part[3] > acc[3]) acc[3] = part[3];
+      prev = in[done + n - 1];
+    }
+  }
+  for (int i = 0; i < 4; ++i) r[i] = acc[i];
+}
+
+uint32_t width_of(uint32_t v) { return v ? 32u - (uint32_t)__builtin_clz(v) : 0u; }
+
+// ---- arbitrary lengths ---------------------------------------------------------
+
+// kind: 0 simdpack_length, 1 simdpackFOR_length
+void *pack_length_host(int kind, uint32_t initvalue, const uint32_t *in, size_t length, void *out, uint32_t bit) {
+  if (bit > 32 || bit == 0) return out;
+  uint8_t *o = static_cast<uint8_t *>(out);
+  Staging &s = staging();
+  std::lock_guard<std::mutex> lock(s.mu);
+  s.init();
+  size_t piece_index = 0;
+  for (size_t done = 0; done < length; done += PIECE, ++piece_index) {
+    const int slot = (int)(piece_index & 1);
+    hipStream_t st = s.stream[slot];
+    const size_t n = length - done < PIECE ? length - done : PIECE;
+    const size_t nbytes = simdcomp_hip_compressedbytes(n, bit);
+    ck(hipStreamSynchronize(st), "hipStreamSynchronize");  // staging slot free again
+    s.reserve(slot, n * 4, nbytes);
+    const uint32_t *d_in = reinterpret_cast<const uint32_t *>(s.din(slot));
+    const bool carry = kind == 1 && done > 0;
+    if (carry) h2d(s.din(slot) - 16, in + done - 4, 16 + n * 4, st);
+    else h2d(s.din(slot), in + done, n * 4, st);
+    if (kind == 0) ckapi(simdcomp_hip_pack_length(d_in, n, s.dout(slot), bit, st), "pack_length");
+    else ckapi(simdcomp_hip_packFOR_length(initvalue, d_in, n, s.dout(slot), bit, carry, st), "packFOR_length");
+    d2h(o + (done / 128) * 16 * bit, s.dout(slot), nbytes, st);
+  }
+  ck(hipStreamSynchronize(s.stream[0]), "hipStreamSynchronize");
+  ck(hipStreamSynchronize(s.stream[1]), "hipStreamSynchronize");
+  return o + simdcomp_hip_compressedbytes(length, bit);
+}
+
+// kind: 0 simdunpack_length, 1 simdunpackFOR_length
+const void *unpack_length_host(int kind, uint32_t initvalue, const void *in, size_t length, uint32_t *out,
+                               uint32_t bit) {
+  if (bit > 32 || length == 0) return in;
+  const uint8_t *p = static_cast<const uint8_t *>(in);
+  Staging &s = staging();
+  std::lock_guard<std::mutex> lock(s.mu);
+  s.init();
+  size_t piece_index = 0;
+  for (size_t done = 0; done < length; done += PIECE, ++piece_index) {
+    const int slot = (int)(piece_index & 1);
+    hipStream_t st = s.stream[slot];
+    const size_t n = length - done < PIECE ? length - done : PIECE;
+    const size_t nbytes = simdcomp_hip_compressedbytes(n, bit);
+    ck(hipStreamSynchronize(st), "hipStreamSynchronize");
+    s.reserve(slot, nbytes, n * 4);
+    h2d(s.din(slot), p + (done / 128) * 16 * bit, nbytes, st);
+    uint32_t *d_out = reinterpret_cast<uint32_t *>(s.dout(slot));
+    if (kind == 0) ckapi(simdcomp_hip_unpack_length(s.din(slot), n, d_out, bit, st), "unpack_length");
+    else ckapi(simdcomp_hip_unpackFOR_length(initvalue, s.din(slot), n, d_out, bit, st), "unpackFOR_length");
+    d2h(out + done, d_out, n * 4, st);
+  }
+  ck(hipStreamSynchronize(s.stream[0]), "hipStreamSynchronize");
+  ck(hipStreamSynchronize(s.stream[1]), "hipStreamSynchronize");
+  return p + simdcomp_hip_compressedbytes(length, bit);
+}
+
+}  // namespace
+
+extern "C" {
+
+// ---- include/simdcomputil.h of the reference ------------------------------------
+uint32_t maxbits(const uint32_t *begin) { return maxbits_length(begin, SIMDBlockSize); }
+
+uint32_t maxbits_length(const uint32_t *in, uint32_t length) {
+  uint32_t r[4];
+  reduce_host(in, length, 0, r);
+  return width_of(r[0]);
+}
+
+uint32_t simdmin(const uint32_t *in) { return simdmin_length(in, SIMDBlockSize); }
+
+uint32_t simdmin_length(const uint32_t *in, uint32_t length) {
+  uint32_t r[4];
+  reduce_host(in, length, 0, r);
+  return r[2];
+}
+
+void simdmaxmin_length(const uint32_t *in, uint32_t length, uint32_t *getmin, uint32_t *getmax) {
+  uint32_t r[4];
+  reduce_host(in, length, 0, r);
+  *getmin = r[2];
+  *getmax = r[3];
+}
+
+void simdmaxmin(const uint32_t *in, uint32_t *getmin, uint32_t *getmax) {
+  simdmaxmin_length(in, SIMDBlockSize, getmin, getmax);
+}
+
+uint32_t simdmaxbitsd1(uint32_t initvalue, const uint32_t *in) {
+  return simdmaxbitsd1_length(initvalue, in, SIMDBlockSize);
+}
+
+uint32_t simdmaxbitsd1_length(uint32_t initvalue, const uint32_t *in, uint32_t length) {
+  uint32_t r[4];
+  reduce_host(in, length, initvalue, r);
+  return width_of(r[1]);
+}
+
+// ---- include/simdbitpacking.h ------------------------------------------------------
+void simdpack(const uint32_t *in, __m128i *out, const uint32_t bit) {
+  block_pack(sc::MODE_PLAIN, true, 0, in, out, bit);
+}
+
+void simdpackwithoutmask(const uint32_t *in, __m128i *out, const uint32_t bit) {
+  block_pack(sc::MODE_PLAIN, false, 0, in, out, bit);
+}
+
+void simdunpack(const __m128i *in, uint32_t *out, const uint32_t bit) {
+  block_unpack(sc::MODE_PLAIN, 0, in, out, bit);
+}
+
+__m128i *simdpack_length(const uint32_t *in, size_t length, __m128i *out, const uint32_t bit) {
+  return static_cast<__m128i *>(pack_length_host(0, 0, in, length, out, bit));
+}
+
+const __m128i *simdunpack_length(const __m128i *in, size_t length, uint32_t *out, const uint32_t bit) {
+  return static_cast<const __m128i *>(unpack_length_host(0, 0, in, length, out, bit));
+}
+
+// The short packer is the unmasked arbitrary-length loop on its own; the frame
+// kernel with base 0 is exactly that loop (src/simdbitpacking.c:14190 and
+// src/simdfor.c:15043 differ only in the subtraction and the padding value).
+__m128i *simdpack_shortlength(const uint32_t *in, int length, __m128i *out, const uint32_t bit) {
+  return static_cast<__m128i *>(pack_length_host(1, 0, in, (size_t)(length < 0 ? 0 : length), out, bit));
+}
+
+const __m128i *simdunpack_shortlength(const __m128i *in, int length, uint32_t *out, const uint32_t bit) {
+  return static_cast<const __m128i *>(unpack_length_host(0, 0, in, (size_t)(length < 0 ? 0 : length), out, bit));
+}
+
+// ---- include/simdintegratedbitpacking.h ------------------------------------------------
+void simdpackd1(uint32_t initvalue, const uint32_t *in, __m128i *out, const uint32_t bit) {
+  block_pack(sc::MODE_D1, true, initvalue, in, out, bit);
+}
+
+void simdpackwithoutmaskd1(uint32_t initvalue, const uint32_t *in, __m128i *out, const uint32_t bit) {
+  block_pack(sc::MODE_D1, false, initvalue, in, out, bit);
+}
+
+void simdunpackd1(uint32_t initvalue, const __m128i *in, uint32_t *out, const uint32_t bit) {
+  block_unpack(sc::MODE_D1, initvalue, in, out, bit);
+}
+
+// ---- include/simdfor.h ---------------------------------------------------------------------
+void simdpackFOR(uint32_t initvalue, const uint32_t *in, __m128i *out, const uint32_t bit) {
+  block_pack(sc::MODE_FOR, false, initvalue, in, out, bit);
+}
+
+void simdunpackFOR(uint32_t initvalue, const __m128i *in, uint32_t *out, const uint32_t bit) {
+  block_unpack(sc::MODE_FOR, initvalue, in, out, bit);
+}
+
+__m128i *simdpackFOR_length(uint32_t initvalue, const uint32_t *in, int length, __m128i *out, const uint32_t bit) {
+  return static_cast<__m128i *>(pack_length_host(1, initvalue, in, (size_t)(length < 0 ? 0 : length), out, bit));
+}
+
+const __m128i *simdunpackFOR_length(uint32_t initvalue, const __m128i *in, int length, uint32_t *out,
+                                    const uint32_t bit) {
+  return static_cast<const __m128i *>(
+      unpack_length_host(1, initvalue, in, (size_t)(length < 0 ? 0 : length), out, bit));
+}
+
+}  // extern "C"
