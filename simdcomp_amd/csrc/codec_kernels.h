@@ -33,6 +33,7 @@ struct PackArgs {
   uint32_t bit;
   uint32_t seed0;
   int carry_blocks;        // GENERIC: hand the end-of-block spill to the next block (whole-array generic loop)
+  size_t chain_base;       // d1 chain mode: index of this call's block 0 in the whole stream (0 = stream start)
   int carry_first;         // GENERIC: block 0 also receives a spill, from the row stored just before `in`
 };
 
@@ -47,8 +48,8 @@ struct ReduceArgs {
   uint32_t seed0;
 };
 
-hipError_t launch_unpack(int mode, bool runtime_width, bool tail, const UnpackArgs &a, hipStream_t st);
-hipError_t launch_pack(int mode, bool masked, bool runtime_width, bool generic, const PackArgs &a, hipStream_t st);
+hipError_t launch_unpack(int mode, bool tail, const UnpackArgs &a, hipStream_t st);
+hipError_t launch_pack(int mode, bool masked, bool generic, const PackArgs &a, hipStream_t st);
 hipError_t launch_reduce(int what, const ReduceArgs &a, hipStream_t st);
 size_t scan_workspace_bytes(size_t nblocks);
 hipError_t launch_payload_offsets(const uint8_t *bits, size_t nblocks, uint64_t *off, uint64_t *total,

@@ -85,7 +85,7 @@ constexpr int BLOCKS_PER_STEP = 8;  // 256 threads = 8 half-waves
 // TAIL: the last block may hold fewer than 128 values (a.length counts values);
 // only rows/values that exist are read and written.
 template <int B, int MODE, int U, bool TAIL>
-__global__ __launch_bounds__(256) void k_unpack(UnpackArgs a) {
+__global__ __launch_bounds__(256) void k_unpack_flex(UnpackArgs a) {
   __shared__ u32x4 lds[4][2][33];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int h = lane >> 5, k = lane & 31;
@@ -202,7 +202,7 @@ constexpr int max_rows_per_word(int b) { return b <= 0 ? 32 : (32 + b - 1) / b; 
 // next word (visible only for out-of-range input), that hand-over also crosses
 // from one block to the next, and only the vectors that hold bits are written.
 template <int B, int MODE, bool MASKED, int U, bool GENERIC>
-__global__ __launch_bounds__(256) void k_pack(PackArgs a) {
+__global__ __launch_bounds__(256) void k_pack_flex(PackArgs a) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int h = lane >> 5, k = lane & 31;
   u32x4 *payload = reinterpret_cast<u32x4 *>(a.payload);
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs a) {
         // block 0 starts from seed0, block k from the last value of block k-1
         if (a.seeds) {
           if (valid[u]) seed[u] = a.seeds[blk[u]];
-        } else if (valid[u] && blk[u] > 0) {
+        } else if (valid[u] && (blk[u] > 0 || a.chain_base > 0)) {
           seed[u] = a.in[blk[u] * 128 - 1];
         }
       } else if constexpr (MODE == MODE_FOR) {
@@ -339,6 +339,281 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs a) {
           payload[vbase[u] + w] = acc;
         }
         if (MODE == MODE_D1 && a.seeds_out && k == 0) a.seeds_out[blk[u]] = seed[u];
+      }
+    }
+  }
+}
+
+
+// ---------------------------------------------------------------------------
+// fast paths: one-shot workgroups, straight-line bodies
+// ---------------------------------------------------------------------------
+// Two measured facts about gfx950 shape these kernels (tools/exp/*.hip are the
+// probes that produced them):
+//
+//  1. Loads and stores of a wave retire through ONE in-order counter (vmcnt).
+//     Behind a divergent branch the compiler can no longer count what is in
+//     flight and waits for everything (s_waitcnt vmcnt(0)) before each LDS
+//     write and each store.  The bodies below have no branch: every block a
+//     workgroup touches exists, every array it indexes is present, lanes past
+//     the end of a payload re-read its last vector instead of being masked.
+//     Ragged ends and optional-argument forms go to the flex kernels.
+//
+//  2. HBM streams fastest when the set of addresses in flight across the chip
+//     is a small window that advances through memory.  A grid of many short
+//     workgroups (each handles 8*U blocks = 4*U KiB of integers and ends) gives
+//     exactly that: the dispatcher hands out block ranges in order as slots
+//     free up.  A persistent grid-stride loop with the same body keeps tens of
+//     MiB in flight at scattered offsets and measured 15-25 % slower; so did
+//     larger per-workgroup footprints.  U is therefore small (1 or 2).
+//
+//   B in 0..32: uniform width, payload of block k at k*16*B; B == -1: per-block
+//   widths a.bits[] and payload offsets a.off[].  a.seeds[] must be an array
+//   for the d1 / FOR modes.  Launch with grid = nblocks / (8*U) workgroups.
+
+template <int B, int MODE, int U>
+__global__ __launch_bounds__(256) void k_unpack_fast(UnpackArgs a) {
+  __shared__ u32x4 lds[4][2][33];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int h = lane >> 5, k = lane & 31;
+  u32x4 *slot = lds[wv][h];
+  const u32x4 *payload = reinterpret_cast<const u32x4 *>(a.payload);
+  constexpr size_t per_iter = (size_t)BLOCKS_PER_STEP * U;
+
+  {
+    const size_t tile = blockIdx.x;
+    const size_t first = tile * per_iter + (size_t)wv * 2 * U + h;
+    uint32_t b[U], seed[U];
+    const u32x4 *src[U];
+    u32x4 ld[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t blk = first + 2 * (size_t)u;
+      if constexpr (B >= 0) {
+        b[u] = B;
+        src[u] = payload + blk * (size_t)B + (k < B ? k : (B ? B - 1 : 0));
+      } else {
+        b[u] = a.bits[blk];
+      }
+      if constexpr (MODE != MODE_PLAIN) seed[u] = a.seeds[blk];
+    }
+    if constexpr (B < 0) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const size_t blk = first + 2 * (size_t)u;
+        const uint32_t last = b[u] ? b[u] - 1 : 0;
+        // a zero-width block has no payload: read (and ignore) its own output area instead
+        src[u] = b[u] ? payload + (size_t)(a.off[blk] >> 4) + ((uint32_t)k < last ? (uint32_t)k : last)
+                      : reinterpret_cast<const u32x4 *>(a.out + blk * 128);
+      }
+    }
+    if constexpr (B != 0) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) ld[u] = *src[u];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t blk = first + 2 * (size_t)u;
+      u32x4 v;
+      if constexpr (B == 0) {
+        v = u32x4{0, 0, 0, 0};
+      } else if constexpr (B == 32) {
+        v = ld[u];
+      } else {
+        wave_lds_fence();
+        slot[k] = ld[u];
+        wave_lds_fence();
+        const uint32_t p = (uint32_t)k * b[u], w = p >> 5, s = p & 31;
+        const u32x4 lo = slot[w], hi = slot[w + 1];
+        const uint32_t m = field_mask(b[u]);
+        v.x = funnel(hi.x, lo.x, s) & m;
+        v.y = funnel(hi.y, lo.y, s) & m;
+        v.z = funnel(hi.z, lo.z, s) & m;
+        v.w = funnel(hi.w, lo.w, s) & m;
+      }
+      if constexpr (MODE == MODE_D1 && B != 32) {
+        u32x4 r = v;
+        r.y += r.x;
+        r.z += r.y;
+        r.w += r.z;
+        const uint32_t incl = half_scan_add(r.w);
+        const uint32_t before = seed[u] + incl - r.w;
+        r.x += before;
+        r.y += before;
+        r.z += before;
+        r.w += before;
+        if constexpr (B < 0) {
+          const bool raw = b[u] == 32;
+          v.x = raw ? v.x : r.x;
+          v.y = raw ? v.y : r.y;
+          v.z = raw ? v.z : r.z;
+          v.w = raw ? v.w : r.w;
+        } else {
+          v = r;
+        }
+      } else if constexpr (MODE == MODE_FOR && B != 32) {
+        const uint32_t add = (B < 0 && b[u] == 32) ? 0u : seed[u];
+        v.x += add;
+        v.y += add;
+        v.z += add;
+        v.w += add;
+      }
+      *reinterpret_cast<u32x4 *>(a.out + blk * 128 + 4 * k) = v;
+    }
+  }
+}
+
+// Decode one already-loaded block per half-wave: LDS exchange, extraction, the
+// mode's arithmetic, one 16-byte store per thread.  `b` is B when B >= 0.
+template <int B, int MODE>
+__device__ __forceinline__ void unpack_finish(const u32x4 ld, const uint32_t b, const uint32_t seed, u32x4 *slot,
+                                              const int k, uint32_t *out_row) {
+  u32x4 v;
+  if constexpr (B == 0) {
+    v = u32x4{0, 0, 0, 0};
+  } else if constexpr (B == 32) {
+    v = ld;
+  } else {
+    wave_lds_fence();
+    slot[k] = ld;
+    wave_lds_fence();
+    const uint32_t p = (uint32_t)k * b, w = p >> 5, s = p & 31;
+    const u32x4 lo = slot[w], hi = slot[w + 1];
+    const uint32_t m = field_mask(b);
+    v.x = funnel(hi.x, lo.x, s) & m;
+    v.y = funnel(hi.y, lo.y, s) & m;
+    v.z = funnel(hi.z, lo.z, s) & m;
+    v.w = funnel(hi.w, lo.w, s) & m;
+  }
+  if constexpr (MODE == MODE_D1 && B != 32) {
+    u32x4 r = v;
+    r.y += r.x;
+    r.z += r.y;
+    r.w += r.z;
+    const uint32_t incl = half_scan_add(r.w);
+    const uint32_t before = seed + incl - r.w;
+    r.x += before;
+    r.y += before;
+    r.z += before;
+    r.w += before;
+    if constexpr (B < 0) {
+      const bool raw = b == 32;
+      v.x = raw ? v.x : r.x;
+      v.y = raw ? v.y : r.y;
+      v.z = raw ? v.z : r.z;
+      v.w = raw ? v.w : r.w;
+    } else {
+      v = r;
+    }
+  } else if constexpr (MODE == MODE_FOR && B != 32) {
+    const uint32_t add = (B < 0 && b == 32) ? 0u : seed;
+    v.x += add;
+    v.y += add;
+    v.z += add;
+    v.w += add;
+  }
+  *reinterpret_cast<u32x4 *>(out_row) = v;
+}
+
+template <int B, int MODE, bool MASKED, int U>
+__global__ __launch_bounds__(256) void k_pack_fast(PackArgs a) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int h = lane >> 5, k = lane & 31;
+  u32x4 *payload = reinterpret_cast<u32x4 *>(a.payload);
+  constexpr size_t per_iter = (size_t)BLOCKS_PER_STEP * U;
+
+  {
+    const size_t tile = blockIdx.x;
+    const size_t first = tile * per_iter + (size_t)wv * 2 * U + h;
+    uint32_t b[U], seed[U];
+    size_t vbase[U];
+    u32x4 x[U], acc[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t blk = first + 2 * (size_t)u;
+      x[u] = *reinterpret_cast<const u32x4 *>(a.in + blk * 128 + 4 * k);
+      if constexpr (B >= 0) {
+        b[u] = B;
+        vbase[u] = blk * (size_t)B;
+      } else {
+        b[u] = a.bits[blk];
+        vbase[u] = (size_t)(a.off[blk] >> 4);
+      }
+      if constexpr (MODE == MODE_D1) {
+        // explicit seeds, or chained from the input: block k starts from in[128k-1], block 0 from seed0
+        const bool start = blk == 0 && a.chain_base == 0;  // first block of the whole stream
+        const uint32_t *sp = a.seeds ? a.seeds + blk : a.in + (start ? 0 : blk * 128 - 1);
+        seed[u] = *sp;
+        if (!a.seeds && start) seed[u] = a.seed0;
+      } else if constexpr (MODE == MODE_FOR) {
+        seed[u] = a.seeds[blk];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t bu = b[u];
+      u32x4 v = x[u];
+      if constexpr (MODE == MODE_D1) {
+        uint32_t prev = dpp0<DPP_WAVE_SHR1>(v.w);
+        prev = k == 0 ? seed[u] : prev;
+        v = u32x4{x[u].x - prev, x[u].y - x[u].x, x[u].z - x[u].y, x[u].w - x[u].z};
+      } else if constexpr (MODE == MODE_FOR) {
+        v -= seed[u];
+      }
+      if constexpr (MASKED) v &= field_mask(bu);
+      const uint32_t p = (uint32_t)k * bu, w = p >> 5, s = p & 31;
+      u32x4 t = v << s;
+      const uint32_t back = (32 - s) & 31;
+      const uint32_t keep = (s + bu > 32) ? 0xFFFFFFFFu : 0u;
+      u32x4 sp = (v >> back) & keep;
+      const uint32_t notfirst = k == 0 ? 0u : 0xFFFFFFFFu;
+      t.x |= dpp0<DPP_WAVE_SHR1>(sp.x) & notfirst;
+      t.y |= dpp0<DPP_WAVE_SHR1>(sp.y) & notfirst;
+      t.z |= dpp0<DPP_WAVE_SHR1>(sp.z) & notfirst;
+      t.w |= dpp0<DPP_WAVE_SHR1>(sp.w) & notfirst;
+#define SC_SEG_STEP(D, CTRL)                                                          \
+  if constexpr (B < 0 || D < max_rows_per_word(B)) {                                  \
+    const uint32_t same = ((((uint32_t)(k - D) * bu) >> 5) == w) ? 0xFFFFFFFFu : 0u;   \
+    t.x |= dpp0<CTRL>(t.x) & same;                                                    \
+    t.y |= dpp0<CTRL>(t.y) & same;                                                    \
+    t.z |= dpp0<CTRL>(t.z) & same;                                                    \
+    t.w |= dpp0<CTRL>(t.w) & same;                                                    \
+  }
+      SC_SEG_STEP(1, DPP_ROW_SHR1)
+      SC_SEG_STEP(2, DPP_ROW_SHR2)
+      SC_SEG_STEP(4, DPP_ROW_SHR4)
+      SC_SEG_STEP(8, DPP_ROW_SHR8)
+#undef SC_SEG_STEP
+      if constexpr (B < 0 || ((15 * B) >> 5) == ((16 * B) >> 5)) {
+        const uint32_t same = (k >= 16 && ((15u * bu) >> 5) == w) ? 0xFFFFFFFFu : 0u;
+        t.x |= dpp0<DPP_ROW_BCAST15, 0xA>(t.x) & same;
+        t.y |= dpp0<DPP_ROW_BCAST15, 0xA>(t.y) & same;
+        t.z |= dpp0<DPP_ROW_BCAST15, 0xA>(t.z) & same;
+        t.w |= dpp0<DPP_ROW_BCAST15, 0xA>(t.w) & same;
+      }
+      acc[u] = t;
+    }
+    // stores last, so that everything above is one straight line
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t bu = b[u];
+      const uint32_t w = ((uint32_t)k * bu) >> 5;
+      if constexpr (B == 32) {
+        payload[vbase[u] + k] = x[u];
+      } else if constexpr (B > 0) {
+        const bool last = (k == 31) || ((((uint32_t)(k + 1) * bu) >> 5) != w);
+        if (last) payload[vbase[u] + w] = acc[u];
+      } else if constexpr (B < 0) {
+        const bool raw = bu == 32;
+        const bool last = (k == 31) || ((((uint32_t)(k + 1) * bu) >> 5) != w);
+        const u32x4 val = raw ? x[u] : acc[u];
+        if (bu != 0 && (raw || last)) payload[vbase[u] + w] = val;  // raw: w == k
+      }
+    }
+    if constexpr (MODE == MODE_D1) {
+      if (a.seeds_out && k == 0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) a.seeds_out[first + 2 * (size_t)u] = seed[u];
       }
     }
   }
@@ -563,88 +838,169 @@ __global__ __launch_bounds__(256) void k_reduce_array(const uint32_t *in, size_t
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
-static int grid_for(size_t nblocks, int U) {
-  const size_t per_iter = (size_t)BLOCKS_PER_STEP * U;
-  size_t tiles = (nblocks + per_iter - 1) / per_iter;
-  const size_t cap = 256 * 8;  // 256 CUs x 8 resident workgroups
+// one tile per workgroup (the kernels' tile loops then run once): see the note
+// on one-shot workgroups above
+static int grid_for_tiles(size_t tiles) {
+  const size_t cap = (size_t)1 << 30;
   if (tiles > cap) tiles = cap;
   if (tiles < 1) tiles = 1;
   return (int)tiles;
 }
 
-constexpr int UNPACK_U = 4;
-constexpr int PACK_U = 4;
+static int grid_for(size_t nblocks, int U) {
+  const size_t per_iter = (size_t)BLOCKS_PER_STEP * U;
+  return grid_for_tiles((nblocks + per_iter - 1) / per_iter);
+}
+
+constexpr int FLEX_U = 2;
 constexpr int REDUCE_U = 4;
 
-template <int MODE, int B>
-static void launch_unpack_fixed(const UnpackArgs &a, hipStream_t st) {
-  hipLaunchKernelGGL((k_unpack<B, MODE, UNPACK_U, false>), dim3(grid_for(a.nblocks, UNPACK_U)), dim3(256), 0, st, a);
+// Steps per workgroup for the one-shot kernels.  Narrow widths are almost pure
+// store traffic and need two blocks per half-wave to cover the payload read
+// behind them; from 13 bits up one block per half-wave measured fastest.
+constexpr int unpack_steps(int b) { return (b < 0 || b <= 12) ? 2 : 1; }
+constexpr int pack_steps(int b) { return (b < 0 || b <= 12) ? 2 : 1; }
+
+// index 0 is the per-block-width instance (B = -1), index 1 + b the uniform width b
+template <int MODE, int BP1>
+static size_t launch_unpack_fast(const UnpackArgs &a, hipStream_t st) {
+  constexpr int U = unpack_steps(BP1 - 1);
+  const size_t nwg = a.nblocks / (BLOCKS_PER_STEP * U);
+  if (nwg) hipLaunchKernelGGL((k_unpack_fast<BP1 - 1, MODE, U>), dim3((unsigned)nwg), dim3(256), 0, st, a);
+  return nwg * BLOCKS_PER_STEP * U;
 }
 
-template <int MODE, int... Bs>
-static void dispatch_unpack(const UnpackArgs &a, hipStream_t st, std::integer_sequence<int, Bs...>) {
-  using fn_t = void (*)(const UnpackArgs &, hipStream_t);
-  static const fn_t table[] = {&launch_unpack_fixed<MODE, Bs>...};
-  table[a.bit](a, st);
+template <int MODE, int... Is>
+static size_t dispatch_unpack_fast(int idx, const UnpackArgs &a, hipStream_t st, std::integer_sequence<int, Is...>) {
+  using fn_t = size_t (*)(const UnpackArgs &, hipStream_t);
+  static const fn_t table[] = {&launch_unpack_fast<MODE, Is>...};
+  return table[idx](a, st);
 }
 
-hipError_t launch_unpack(int mode, bool runtime_width, bool tail, const UnpackArgs &a, hipStream_t st) {
-  if (a.nblocks == 0) return hipSuccess;
-  if (runtime_width || tail) {
-    const dim3 g(grid_for(a.nblocks, UNPACK_U)), t(256);
+static void launch_unpack_flex(int mode, bool tail, const UnpackArgs &a, hipStream_t st) {
+  const dim3 g(grid_for(a.nblocks, FLEX_U)), t(256);
 #define SC_RT(MODE_)                                                                         \
-  if (tail) hipLaunchKernelGGL((k_unpack<-1, MODE_, UNPACK_U, true>), g, t, 0, st, a);        \
-  else hipLaunchKernelGGL((k_unpack<-1, MODE_, UNPACK_U, false>), g, t, 0, st, a);
-    if (mode == MODE_PLAIN) { SC_RT(MODE_PLAIN) }
-    else if (mode == MODE_D1) { SC_RT(MODE_D1) }
-    else { SC_RT(MODE_FOR) }
+  if (tail) hipLaunchKernelGGL((k_unpack_flex<-1, MODE_, FLEX_U, true>), g, t, 0, st, a);     \
+  else hipLaunchKernelGGL((k_unpack_flex<-1, MODE_, FLEX_U, false>), g, t, 0, st, a);
+  if (mode == MODE_PLAIN) { SC_RT(MODE_PLAIN) }
+  else if (mode == MODE_D1) { SC_RT(MODE_D1) }
+  else { SC_RT(MODE_FOR) }
 #undef SC_RT
-  } else {
-    using seq = std::make_integer_sequence<int, 33>;
-    if (mode == MODE_PLAIN) dispatch_unpack<MODE_PLAIN>(a, st, seq{});
-    else if (mode == MODE_D1) dispatch_unpack<MODE_D1>(a, st, seq{});
-    else dispatch_unpack<MODE_FOR>(a, st, seq{});
+}
+
+// one launch covers at most this many blocks (keeps grid.x far below 2^31 workgroups)
+constexpr size_t MAX_BLOCKS_PER_LAUNCH = (size_t)1 << 30;
+
+hipError_t launch_unpack(int mode, bool tail, const UnpackArgs &a, hipStream_t st) {
+  if (a.nblocks == 0) return hipSuccess;
+  const bool mixed = a.bits != nullptr && a.off != nullptr;
+  const bool uniform = a.bits == nullptr && a.off == nullptr;
+  const bool seeds_ok = mode == MODE_PLAIN || a.seeds != nullptr;
+  if (tail || !(mixed || uniform) || !seeds_ok) {
+    launch_unpack_flex(mode, tail, a, st);
+    return hipGetLastError();
+  }
+  using seq = std::make_integer_sequence<int, 34>;
+  const int idx = mixed ? 0 : 1 + (int)a.bit;
+  UnpackArgs r = a;
+  while (r.nblocks) {
+    UnpackArgs c = r;
+    if (c.nblocks > MAX_BLOCKS_PER_LAUNCH) c.nblocks = MAX_BLOCKS_PER_LAUNCH;
+    size_t done;
+    if (mode == MODE_PLAIN) done = dispatch_unpack_fast<MODE_PLAIN>(idx, c, st, seq{});
+    else if (mode == MODE_D1) done = dispatch_unpack_fast<MODE_D1>(idx, c, st, seq{});
+    else done = dispatch_unpack_fast<MODE_FOR>(idx, c, st, seq{});
+    if (done == 0) {  // fewer blocks than one workgroup handles: ragged end
+      launch_unpack_flex(mode, false, r, st);
+      break;
+    }
+    r.nblocks -= done;
+    r.length = r.nblocks * 128;
+    r.out += done * 128;
+    if (r.seeds) r.seeds += done;
+    if (mixed) {
+      r.bits += done;
+      r.off += done;
+    } else {
+      r.payload = static_cast<const uint8_t *>(r.payload) + done * 16 * (size_t)a.bit;
+    }
   }
   return hipGetLastError();
 }
 
-template <int MODE, bool MASKED, int B>
-static void launch_pack_fixed(const PackArgs &a, hipStream_t st) {
-  hipLaunchKernelGGL((k_pack<B, MODE, MASKED, PACK_U, false>), dim3(grid_for(a.nblocks, PACK_U)), dim3(256), 0, st, a);
+template <int MODE, bool MASKED, int BP1>
+static size_t launch_pack_fast(const PackArgs &a, hipStream_t st) {
+  constexpr int U = pack_steps(BP1 - 1);
+  const size_t nwg = a.nblocks / (BLOCKS_PER_STEP * U);
+  if (nwg) hipLaunchKernelGGL((k_pack_fast<BP1 - 1, MODE, MASKED, U>), dim3((unsigned)nwg), dim3(256), 0, st, a);
+  return nwg * BLOCKS_PER_STEP * U;
 }
 
-template <int MODE, bool MASKED, int... Bs>
-static void dispatch_pack(const PackArgs &a, hipStream_t st, std::integer_sequence<int, Bs...>) {
-  using fn_t = void (*)(const PackArgs &, hipStream_t);
-  static const fn_t table[] = {&launch_pack_fixed<MODE, MASKED, Bs>...};
-  table[a.bit](a, st);
+template <int MODE, bool MASKED, int... Is>
+static size_t dispatch_pack_fast(int idx, const PackArgs &a, hipStream_t st, std::integer_sequence<int, Is...>) {
+  using fn_t = size_t (*)(const PackArgs &, hipStream_t);
+  static const fn_t table[] = {&launch_pack_fast<MODE, MASKED, Is>...};
+  return table[idx](a, st);
 }
 
-hipError_t launch_pack(int mode, bool masked, bool runtime_width, bool generic, const PackArgs &a, hipStream_t st) {
-  if (a.nblocks == 0) return hipSuccess;
-  const dim3 g(grid_for(a.nblocks, PACK_U)), t(256);
-  using seq = std::make_integer_sequence<int, 33>;
+static void launch_pack_flex(int mode, bool masked, bool generic, const PackArgs &a, hipStream_t st) {
+  const dim3 g(grid_for(a.nblocks, FLEX_U)), t(256);
   if (generic) {
     // arbitrary-length packer: unmasked by definition (plain or frame-of-reference)
-    if (mode == MODE_FOR) hipLaunchKernelGGL((k_pack<-1, MODE_FOR, false, PACK_U, true>), g, t, 0, st, a);
-    else hipLaunchKernelGGL((k_pack<-1, MODE_PLAIN, false, PACK_U, true>), g, t, 0, st, a);
-  } else if (runtime_width) {
+    if (mode == MODE_FOR) hipLaunchKernelGGL((k_pack_flex<-1, MODE_FOR, false, FLEX_U, true>), g, t, 0, st, a);
+    else hipLaunchKernelGGL((k_pack_flex<-1, MODE_PLAIN, false, FLEX_U, true>), g, t, 0, st, a);
+    return;
+  }
 #define SC_RT(MODE_)                                                                           \
-  if (masked) hipLaunchKernelGGL((k_pack<-1, MODE_, true, PACK_U, false>), g, t, 0, st, a);     \
-  else hipLaunchKernelGGL((k_pack<-1, MODE_, false, PACK_U, false>), g, t, 0, st, a);
-    if (mode == MODE_PLAIN) { SC_RT(MODE_PLAIN) }
-    else if (mode == MODE_D1) { SC_RT(MODE_D1) }
-    else { SC_RT(MODE_FOR) }
+  if (masked) hipLaunchKernelGGL((k_pack_flex<-1, MODE_, true, FLEX_U, false>), g, t, 0, st, a); \
+  else hipLaunchKernelGGL((k_pack_flex<-1, MODE_, false, FLEX_U, false>), g, t, 0, st, a);
+  if (mode == MODE_PLAIN) { SC_RT(MODE_PLAIN) }
+  else if (mode == MODE_D1) { SC_RT(MODE_D1) }
+  else { hipLaunchKernelGGL((k_pack_flex<-1, MODE_FOR, false, FLEX_U, false>), g, t, 0, st, a); }
 #undef SC_RT
-  } else {
+}
+
+hipError_t launch_pack(int mode, bool masked, bool generic, const PackArgs &a, hipStream_t st) {
+  if (a.nblocks == 0) return hipSuccess;
+  const bool mixed = a.bits != nullptr && a.off != nullptr;
+  const bool uniform = a.bits == nullptr && a.off == nullptr;
+  const bool seeds_ok = mode != MODE_FOR || a.seeds != nullptr;
+  if (mode == MODE_FOR) masked = false;
+  if (generic || !(mixed || uniform) || !seeds_ok) {
+    launch_pack_flex(mode, masked, generic, a, st);
+    return hipGetLastError();
+  }
+  using seq = std::make_integer_sequence<int, 34>;
+  const int idx = mixed ? 0 : 1 + (int)a.bit;
+  PackArgs r = a;
+  while (r.nblocks) {
+    PackArgs c = r;
+    if (c.nblocks > MAX_BLOCKS_PER_LAUNCH) c.nblocks = MAX_BLOCKS_PER_LAUNCH;
+    size_t done;
     if (mode == MODE_PLAIN) {
-      if (masked) dispatch_pack<MODE_PLAIN, true>(a, st, seq{});
-      else dispatch_pack<MODE_PLAIN, false>(a, st, seq{});
+      done = masked ? dispatch_pack_fast<MODE_PLAIN, true>(idx, c, st, seq{})
+                    : dispatch_pack_fast<MODE_PLAIN, false>(idx, c, st, seq{});
     } else if (mode == MODE_D1) {
-      if (masked) dispatch_pack<MODE_D1, true>(a, st, seq{});
-      else dispatch_pack<MODE_D1, false>(a, st, seq{});
+      done = masked ? dispatch_pack_fast<MODE_D1, true>(idx, c, st, seq{})
+                    : dispatch_pack_fast<MODE_D1, false>(idx, c, st, seq{});
     } else {
-      dispatch_pack<MODE_FOR, false>(a, st, seq{});
+      done = dispatch_pack_fast<MODE_FOR, false>(idx, c, st, seq{});
+    }
+    if (done == 0) {
+      launch_pack_flex(mode, masked, false, r, st);
+      break;
+    }
+    r.nblocks -= done;
+    r.length = r.nblocks * 128;
+    r.in += done * 128;
+    r.chain_base += done;
+    if (r.seeds) r.seeds += done;
+    if (r.seeds_out) r.seeds_out += done;
+    if (mixed) {
+      r.bits += done;
+      r.off += done;
+    } else {
+      r.payload = static_cast<uint8_t *>(r.payload) + done * 16 * (size_t)a.bit;
     }
   }
   return hipGetLastError();

@@ -56,7 +56,7 @@ int do_pack(int mode, int masked, uint32_t initvalue, const uint32_t *seeds, con
   a.bit = bit;
   a.seed0 = initvalue;
   a.carry_blocks = 0;
-  return hip_result(sc::launch_pack(mode, masked != 0 && mode != SIMDCOMP_HIP_FOR, mixed || off != nullptr, false, a,
+  return hip_result(sc::launch_pack(mode, masked != 0 && mode != SIMDCOMP_HIP_FOR, false, a,
                                     as_stream(stream)),
                     "pack launch");
 }
@@ -76,7 +76,7 @@ int do_unpack(int mode, uint32_t seed0, const uint32_t *seeds, const void *paylo
   a.length = nblocks * 128;
   a.bit = bit;
   a.seed0 = seed0;
-  return hip_result(sc::launch_unpack(mode, mixed || off != nullptr, false, a, as_stream(stream)), "unpack launch");
+  return hip_result(sc::launch_unpack(mode, false, a, as_stream(stream)), "unpack launch");
 }
 
 }  // namespace
@@ -215,7 +215,7 @@ int simdcomp_hip_pack_length(const uint32_t *d_in, size_t length, void *d_out, u
     a.nblocks = 1;
     a.length = rest;
     a.bit = bit;
-    return hip_result(sc::launch_pack(sc::MODE_PLAIN, false, true, true, a, as_stream(stream)), "pack tail launch");
+    return hip_result(sc::launch_pack(sc::MODE_PLAIN, false, true, a, as_stream(stream)), "pack tail launch");
   }
   return SIMDCOMP_HIP_OK;
 }
@@ -238,7 +238,7 @@ static int unpack_length_common(int mode, uint32_t initvalue, const void *d_in, 
     a.length = rest;
     a.bit = bit;
     a.seed0 = initvalue;
-    return hip_result(sc::launch_unpack(mode, true, true, a, as_stream(stream)), "unpack tail launch");
+    return hip_result(sc::launch_unpack(mode, true, a, as_stream(stream)), "unpack tail launch");
   }
   return SIMDCOMP_HIP_OK;
 }
@@ -264,7 +264,7 @@ int simdcomp_hip_packFOR_length(uint32_t initvalue, const uint32_t *d_in, size_t
   a.seed0 = initvalue;
   a.carry_blocks = 1;
   a.carry_first = carry_in != 0;
-  return hip_result(sc::launch_pack(sc::MODE_FOR, false, true, true, a, as_stream(stream)), "packFOR_length launch");
+  return hip_result(sc::launch_pack(sc::MODE_FOR, false, true, a, as_stream(stream)), "packFOR_length launch");
 }
 
 int simdcomp_hip_unpackFOR_length(uint32_t initvalue, const void *d_in, size_t length, uint32_t *d_out,

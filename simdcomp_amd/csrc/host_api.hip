@@ -104,7 +104,7 @@ void block_pack(int mode, bool masked, uint32_t initvalue, const uint32_t *in, v
   a.length = 128;
   a.bit = bit;
   a.seed0 = initvalue;  // seeds == nullptr: block 0 of a chained d1 stream / uniform frame base
-  ck(sc::launch_pack(mode, masked, false, false, a, st), "pack launch");
+  ck(sc::launch_pack(mode, masked, false, a, st), "pack launch");
   d2h(out, s.dout(0), 16 * (size_t)bit, st);
   ck(hipStreamSynchronize(st), "hipStreamSynchronize");
 }
@@ -123,7 +123,7 @@ void block_unpack(int mode, uint32_t initvalue, const void *in, uint32_t *out, u
   a.length = 128;
   a.bit = bit;
   a.seed0 = initvalue;
-  ck(sc::launch_unpack(mode, false, false, a, st), "unpack launch");
+  ck(sc::launch_unpack(mode, false, a, st), "unpack launch");
   d2h(out, s.dout(0), 512, st);
   ck(hipStreamSynchronize(st), "hipStreamSynchronize");
 }
