@@ -1,0 +1,261 @@
+#!/usr/bin/env python3
+"""Headline benchmark: device-resident simdunpackd1 over sorted posting lists.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2]): per GPU, a sorted list of 2^30 docIDs cut
+into 128-integer blocks with stored per-block offsets, encoded with
+simdpackwithoutmaskd1 at one uniform width b, for every b = 1..32.  One STEP
+decodes the whole per-GPU corpus once at each of the 32 widths (32 launches of
+simdcomp_hip_unpackd1, 2^30 integers each); inputs (payloads, offsets) and
+outputs are resident in HBM.  value = decoded integers per second over all
+GPUs.  Blocks are independent, so with N GPUs the global corpus of N*2^30
+docIDs is split by block range (simdcomp_hip_partition) and no collective is on
+the data path; the only communication is the final verification all-reduce
+(mismatch count and checksum).
+
+Extra objects on the JSON line:
+  roofline      HBM roofline of the decode kernel: algorithmic bytes
+                (512 + 16 b + 4 per block) / launch time from HIP events
+                recorded on the launch stream inside the timed region,
+                aggregated over the 32 widths, with the per-width table;
+  cpu_baseline  the reference's own simdunpackd1 (compiled from its sources
+                into oracle/_ref, SSE4.1) timed on this host on a bounded
+                sample, 1 thread (and all cores as `all_cores`);
+  host_to_host  the same decode including pinned H2D/D2H copies (rank 0 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from simdcomp_amd import binding, codec  # noqa: E402  (fails loudly if the HIP library is missing)
+
+HBM_PEAK = 8.0e12  # bytes/s, MI355X HBM3E nominal
+WIDTHS = list(range(1, 33))
+
+
+def algorithmic_bytes(nblocks, b):
+    """Bytes simdunpackd1 must move for nblocks blocks: payload read + output
+    written + one 4-byte offset per block."""
+    return nblocks * (512 + 16 * b + 4)
+
+
+def build_corpus(nblocks, b, seed, dev):
+    """Sorted docIDs with random gaps below 2^b (the distribution of the
+    reference's d1 benchmark generator, benchmarks/bitpackingbenchmark.c:44-53),
+    encoded on the device.  Returns (payload, offsets, number of decode
+    mismatches, checksum of the decoded array)."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    n = nblocks * 128
+    gaps = torch.randint(0, 2 ** 31 - 1, (n,), dtype=torch.int32, device=dev, generator=g)
+    if b < 31:
+        gaps &= (1 << b) - 1
+    elif b == 32:
+        gaps = gaps * 2 + (gaps & 1)  # use all 32 bits
+    ids = torch.cumsum(gaps, 0, dtype=torch.int32)  # wraps mod 2^32 like the reference's uint32 sums
+    del gaps
+    offsets = torch.empty(nblocks, dtype=torch.int32, device=dev)
+    payload = codec.packd1(ids, b, initvalue=0, masked=False, initvalues_out=offsets)
+    back = codec.unpackd1(offsets, payload, nblocks, b)
+    acc = codec.checksum(back, other=ids)
+    torch.cuda.synchronize()
+    return payload, offsets, acc
+
+
+def cpu_baseline(log2n=26, reps=3):
+    """The reference's simdunpackd1 on this host's cores (bounded sample)."""
+    try:
+        import oracle
+    except Exception as e:  # pragma: no cover
+        return {"value": None, "unit": "int32/s", "cores": 0, "kind": "none", "sample": f"oracle unavailable: {e}"}
+    orc = oracle.Oracle()
+    if oracle.have_ref():
+        lib, kind, fn = oracle.Reference(), "reference", None
+        fn = lib._unpackd1
+    else:
+        kind, fn = "port", orc._unpackd1
+    n = 1 << log2n
+    nblk = n // 128
+    rng = np.random.default_rng(1)
+    out = np.empty(n, dtype=np.uint32)
+    seeds = rng.integers(0, 2 ** 32, nblk, dtype=np.uint32)
+    ncores = min(16, os.cpu_count() or 1)
+    t1 = tn = 0.0
+    for b in WIDTHS:
+        payload = rng.integers(0, 256, nblk * 16 * b, dtype=np.uint8)
+        t1 += orc.time_blocks(0, fn, seeds, payload, out, b, nblk, 1, reps)
+        tn += orc.time_blocks(0, fn, seeds, payload, out, b, nblk, ncores, reps)
+    total = n * len(WIDTHS)
+    return {"value": total / t1, "unit": "int32/s", "cores": 1, "kind": kind,
+            "sample": f"simdunpackd1 over 2^{log2n} ints (out of cache) at each b=1..32, best of {reps}, "
+                      f"{'oracle/_ref built -O3 -msse4.1' if kind == 'reference' else 'scalar restatement'}",
+            "all_cores": {"value": total / tn, "cores": ncores}}
+
+
+def host_to_host(dev, log2n=28, widths=(1, 8, 16, 32)):
+    """Decode that starts and ends in pinned host memory: H2D payload+offsets,
+    kernel, D2H integers, pipelined in 2^24-integer pieces over two streams."""
+    n = 1 << log2n
+    nblk = n // 128
+    piece = 1 << 17  # blocks per piece (2^24 integers)
+    res = {}
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    h_out = torch.empty(n, dtype=torch.int32, pin_memory=True)
+    h_off = torch.empty(nblk, dtype=torch.int32, pin_memory=True).fill_(12345)
+    for b in widths:
+        h_pay = torch.empty(nblk * 16 * b, dtype=torch.uint8, pin_memory=True).fill_(0x5B)
+        d_pay = [torch.empty(piece * 16 * b, dtype=torch.uint8, device=dev) for _ in range(2)]
+        d_off = [torch.empty(piece, dtype=torch.int32, device=dev) for _ in range(2)]
+        d_out = [torch.empty(piece * 128, dtype=torch.int32, device=dev) for _ in range(2)]
+
+        def run():
+            for i, first in enumerate(range(0, nblk, piece)):
+                s = i & 1
+                with torch.cuda.stream(streams[s]):
+                    cnt = min(piece, nblk - first)
+                    d_pay[s][: cnt * 16 * b].copy_(h_pay[first * 16 * b:(first + cnt) * 16 * b], non_blocking=True)
+                    d_off[s][:cnt].copy_(h_off[first:first + cnt], non_blocking=True)
+                    codec.unpackd1(d_off[s], d_pay[s], cnt, b, out=d_out[s])
+                    h_out[first * 128:(first + cnt) * 128].copy_(d_out[s][: cnt * 128], non_blocking=True)
+            torch.cuda.synchronize()
+
+        run()
+        best = 1e9
+        for _ in range(3):
+            t0 = time.perf_counter()
+            run()
+            best = min(best, time.perf_counter() - t0)
+        res[str(b)] = {"Gint/s": round(n / best / 1e9, 2), "GB/s_over_pcie": round((n * 4 + nblk * (16 * b + 4)) / best / 1e9, 1)}
+        del h_pay, d_pay
+    return {"ints": n, "pinned": True, "per_width": res}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--log2n", type=int, default=30, help="log2 of docIDs per GPU")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-h2h", action="store_true", help="skip the host-to-host leg")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    # block-range shard of the global corpus (weak scaling: 2^log2n docIDs per GPU)
+    total_blocks = world * ((1 << a.log2n) // 128)
+    first, nblocks = codec.partition(total_blocks, world, rank)
+
+    corpora = {}
+    verify = torch.zeros(2, dtype=torch.int64, device=dev)
+    for b in WIDTHS:
+        payload, offsets, acc = build_corpus(nblocks, b, seed=1000 * (first % 100003) + b, dev=dev)
+        corpora[b] = (payload, offsets)
+        verify += acc
+    out = torch.empty(nblocks * 128, dtype=torch.int32, device=dev)
+
+    def step(events=None):
+        for b in WIDTHS:
+            payload, offsets = corpora[b]
+            if events is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            codec.unpackd1(offsets, payload, nblocks, b, out=out)
+            if events is not None:
+                e1.record()
+                events.append((b, e0, e1))
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    events = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step(events)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(verify, op=dist.ReduceOp.SUM)  # the verification reduction (RCCL)
+    elapsed = float(t.item())
+
+    # per-width kernel time from the events recorded in the timed region
+    per_b = {b: [] for b in WIDTHS}
+    for b, e0, e1 in events:
+        per_b[b].append(e0.elapsed_time(e1) * 1e-3)
+    table = {}
+    tot_bytes = tot_time = 0.0
+    for b in WIDTHS:
+        avg = sum(per_b[b]) / len(per_b[b])
+        nbytes = algorithmic_bytes(nblocks, b)
+        tot_bytes += nbytes
+        tot_time += avg
+        table[str(b)] = {"ms": round(avg * 1e3, 4), "GB/s": round(nbytes / avg / 1e9, 1),
+                         "frac": round(nbytes / avg / HBM_PEAK, 4), "Gint/s": round(nblocks * 128 / avg / 1e9, 1)}
+
+    if rank == 0:
+        ints_per_step = world * nblocks * 128 * len(WIDTHS)
+        achieved = tot_bytes / tot_time
+        line = {
+            "metric": "device-resident decoded int32/s (simdunpackd1, b=1..32)",
+            "value": ints_per_step * a.steps / elapsed,
+            "unit": "int32/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: sorted posting lists, 2^%d docIDs per GPU, random gaps < 2^b, "
+                                   "simdunpackd1 with stored per-block offsets, one launch per width b=1..32 per step"
+                                   % a.log2n,
+                       "ints_per_gpu": nblocks * 128, "widths": "1..32", "sharding": "block range, no data-path collective"},
+            "verification": {"decode_mismatches": int(verify[1].item()), "checksum": int(verify[0].item()) & (2 ** 64 - 1)},
+            "roofline": {"bound": "hbm", "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK, 4), "traffic": None,
+                         "kernel": "sc::k_unpack_fast<b, d1> (one instantiation per width), aggregate over b=1..32",
+                         "bytes_per_block": "512 + 16*b + 4",
+                         "min_frac": min(v["frac"] for v in table.values()),
+                         "per_width": table},
+        }
+        if not a.no_cpu:
+            line["cpu_baseline"] = cpu_baseline()
+        if not a.no_h2h:
+            del corpora
+            torch.cuda.empty_cache()
+            line["host_to_host"] = host_to_host(dev)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
