@@ -72,6 +72,21 @@ def build_corpus(nblocks, b, seed, dev):
     return payload, offsets, acc
 
 
+def measured_traffic(nblocks):
+    """Average HBM bytes per launch from the committed PMC summary (separate
+    rocprofv3 --pmc passes of this same command, tools/summarize_profiles.py);
+    None when the summary is absent or was taken at another corpus size."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
+    try:
+        doc = json.load(open(path))
+        rows = [doc["per_width"][str(b)] for b in WIDTHS]
+        if any(abs(r["WRITE_SIZE_KB"] * 1024 - nblocks * 512) > nblocks for r in rows):
+            return None
+        return sum(r["hbm_bytes"] for r in rows) / len(rows)
+    except Exception:
+        return None
+
+
 def cpu_baseline(log2n=26, reps=3):
     """The reference's simdunpackd1 on this host's cores (bounded sample)."""
     try:
@@ -239,7 +254,8 @@ def main():
                        "ints_per_gpu": nblocks * 128, "widths": "1..32", "sharding": "block range, no data-path collective"},
             "verification": {"decode_mismatches": int(verify[1].item()), "checksum": int(verify[0].item()) & (2 ** 64 - 1)},
             "roofline": {"bound": "hbm", "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK, 4), "traffic": measured_traffic(nblocks),
+                         "algorithmic_bytes_per_launch": tot_bytes / len(WIDTHS),
                          "kernel": "sc::k_unpack_fast<b, d1> (one instantiation per width), aggregate over b=1..32",
                          "bytes_per_block": "512 + 16*b + 4",
                          "min_frac": min(v["frac"] for v in table.values()),

@@ -1,0 +1,112 @@
+"""CPU-only checks of the C-ABI boundary: the shared library loads without a
+GPU, exports every function the two headers declare, and its host-side
+arithmetic (sizes, partitioner, single-value accessors) matches the oracle.
+No kernel is launched here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from simdcomp_amd import binding, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"^\s*#.*$", "", text, flags=re.M)
+    names = re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{]*\)\s*;", text)
+    return sorted(set(n for n in names if n not in ("defined",)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = binding.load()
+    dev = declared_functions("simdcomp_hip.h")
+    host = declared_functions("simdcomp.h")
+    assert len(dev) >= 24 and len(host) >= 29
+    for name in dev + host:
+        assert hasattr(lib, name), f"{name} is declared in include/ but not exported"
+    # and the binding tables cover the headers exactly
+    assert sorted(binding.DEVICE_API) == dev
+    assert sorted(binding.HOST_API) == host
+
+
+def test_version_and_sizes(orc):
+    lib = binding.lib()
+    assert lib.simdcomp_hip_version() >= 100
+    for bit in range(33):
+        for n in (0, 1, 3, 4, 5, 127, 128, 129, 130, 9999, 2 ** 30, 2 ** 33 + 5):
+            assert lib.simdcomp_hip_compressedbytes(n, bit) == orc.compressedbytes64(n, bit)
+        for n in (0, 1, 5, 130, 9999):
+            assert lib.simdpack_compressedbytes(n, bit) == orc.compressedbytes(n, bit)
+            assert lib.simdpackFOR_compressedbytes(n, bit) == orc.compressedbytesFOR(n, bit)
+    assert lib.simdcomp_hip_compressedbytes(9999, 14) == 17504  # example.c prints this size
+    for v in (0, 1, 2, 3, 255, 256, 0x7FFFFFFF, 0x80000000, 0xFFFFFFFF):
+        assert lib.bits(v) == orc.bits(v)
+
+
+def test_partition_block_ranges():
+    lib = binding.lib()
+    first, count = C.c_size_t(), C.c_size_t()
+    for nblocks in (0, 1, 7, 8, 1000003, 2 ** 23, 125000000):
+        for nparts in (1, 2, 3, 4, 8):
+            end = 0
+            sizes = []
+            for p in range(nparts):
+                assert lib.simdcomp_hip_partition(nblocks, nparts, p, C.byref(first), C.byref(count)) == 0
+                assert first.value == end
+                end = first.value + count.value
+                sizes.append(count.value)
+            assert end == nblocks and max(sizes) - min(sizes) <= 1
+    assert lib.simdcomp_hip_partition(10, 0, 0, C.byref(first), C.byref(count)) < 0
+    assert lib.simdcomp_hip_partition(10, 2, 2, C.byref(first), C.byref(count)) < 0
+
+
+def test_partition_by_bytes_balances_cost():
+    lib = binding.lib()
+    nblk = 100000
+    widths = synth.skewed_widths(5, nblk, 0, 32).astype(np.uint64)
+    widths[: nblk // 2] = 1  # first half cheap, second half expensive
+    off = np.concatenate([[0], np.cumsum(widths * 16)]).astype(np.uint64)
+    first, count = C.c_size_t(), C.c_size_t()
+    cost = lambda a, b: int(off[b] - off[a]) + 512 * (b - a)
+    for nparts in (1, 2, 4, 8):
+        end, costs = 0, []
+        for p in range(nparts):
+            assert lib.simdcomp_hip_partition_by_bytes(off.ctypes.data, nblk, nparts, p, C.byref(first),
+                                                       C.byref(count)) == 0
+            assert first.value == end
+            end = first.value + count.value
+            costs.append(cost(first.value, end))
+        assert end == nblk
+        assert max(costs) - min(costs) <= 2 * (512 + 512)  # within a couple of blocks of perfect balance
+
+
+@pytest.mark.parametrize("bit", range(33))
+def test_single_value_accessors(orc, bit):
+    """simdselectFOR / simdsearchwithlengthFOR / simdfastset(FOR) are host routines of the library."""
+    lib = binding.lib()
+    x = np.sort(synth.random_bits(11, 128, bit))
+    base = 1000
+    xf = (x + np.uint32(base)).astype(np.uint32)
+    comp = np.concatenate([orc.simdpackFOR(base, xf, bit), np.zeros(32, np.uint8)])
+    for slot in range(128):
+        assert lib.simdselectFOR(base, comp.ctypes.data, bit, slot) == int(xf[slot]) == \
+            orc.simdselectFOR(base, comp, bit, slot)
+    res = C.c_uint32()
+    for key in list(xf[::9]) + [0, base, int(xf[-1]) + 1, 0xFFFFFFFF]:
+        for length in (128, 77, 1):
+            pos = lib.simdsearchwithlengthFOR(base, comp.ctypes.data, bit, length, int(key), C.byref(res))
+            assert (pos, res.value) == orc.simdsearchwithlengthFOR(base, comp, bit, length, int(key))
+    newv = synth.random_bits(12, 128, bit)
+    mine, want = comp.copy(), comp[: 16 * bit].copy()
+    for idx in (0, 1, 5, 31, 64, 126, 127):
+        lib.simdfastset(mine.ctypes.data, bit, int(newv[idx]), idx)
+        want = orc.simdfastset(want, bit, int(newv[idx]), idx)
+        assert np.array_equal(mine[: 16 * bit], want)
+        lib.simdfastsetFOR(base, mine.ctypes.data, bit, int(newv[idx]) + base, idx)
+        want = orc.simdfastsetFOR(base, want, bit, int(newv[idx]) + base, idx)
+        assert np.array_equal(mine[: 16 * bit], want)

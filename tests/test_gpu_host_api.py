@@ -1,0 +1,195 @@
+"""The reference-signature host API (include/simdcomp.h) of libsimdcomp_hip.so,
+called through ctypes with HOST arrays exactly as a C caller of the reference
+would, compared with the golden fixtures and the oracle.  The tests read like
+the reference's own (tests/unit.c): pack, check the returned pointer against
+*_compressedbytes, unpack, compare."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import golden_util as G
+from simdcomp_amd import binding, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return binding.lib()
+
+
+def p(a):
+    return a.ctypes.data
+
+
+def test_blocks_against_golden(lib):
+    g = G.load("blocks.npz")
+    for bit in range(33):
+        for kind in range(3):
+            x = g["x"][bit, kind].copy()
+            iv = int(g["init"][bit, kind])
+            outs = []
+            for fn, seeded in ((lib.simdpack, False), (lib.simdpackwithoutmask, False), (lib.simdpackd1, True),
+                               (lib.simdpackwithoutmaskd1, True), (lib.simdpackFOR, True)):
+                buf = np.full(512 + 16, 0xA5, np.uint8)
+                if seeded:
+                    fn(iv, p(x), p(buf), bit)
+                else:
+                    fn(p(x), p(buf), bit)
+                assert (buf[16 * bit:] == 0xA5).all(), "packer wrote past b vectors"
+                outs.append(buf[:16 * bit].copy())
+            for j, o in enumerate(outs):
+                want = g["packed"][bit, kind, j, :16 * bit]
+                assert np.array_equal(o, want), (G.PACK_NAMES[j], bit, kind)
+                src = np.concatenate([want, np.zeros(16, np.uint8)])
+                out = np.zeros(128, np.uint32)
+                lib.simdunpack(p(src), p(out), bit)
+                assert np.array_equal(out, g["unpacked"][bit, kind, j, 0])
+                lib.simdunpackd1(iv, p(src), p(out), bit)
+                assert np.array_equal(out, g["unpacked"][bit, kind, j, 1])
+                lib.simdunpackFOR(iv, p(src), p(out), bit)
+                assert np.array_equal(out, g["unpacked"][bit, kind, j, 2])
+            lo, hi = C.c_uint32(), C.c_uint32()
+            lib.simdmaxmin(p(x), C.byref(lo), C.byref(hi))
+            red = [lib.maxbits(p(x)), lib.simdmaxbitsd1(iv, p(x)), lo.value, hi.value]
+            assert red == g["red"][bit, kind].tolist()
+            assert lib.simdmin(p(x)) == lo.value
+
+
+def test_bit_above_32_does_nothing(lib):
+    x = synth.rand_u32(1, 128)
+    buf = np.full(600, 0xA5, np.uint8)
+    lib.simdpack(p(x), p(buf), 33)
+    lib.simdpackd1(7, p(x), p(buf), 40)
+    assert (buf == 0xA5).all()
+    out = np.full(128, 0xDEADBEEF, np.uint32)
+    lib.simdunpack(p(buf), p(out), 33)
+    assert (out == 0xDEADBEEF).all()
+
+
+def test_unaligned_pointers_like_example_c(lib, orc):
+    """example.c:68-72 feeds payloads shifted by the 1-byte width header."""
+    x = synth.sorted_gaps(5, 128, 11, first=100)
+    raw = np.zeros(1 + 16 * 11 + 8, np.uint8)
+    b = lib.simdmaxbitsd1(100, p(x))
+    assert b == orc.simdmaxbitsd1(100, x)
+    raw[0] = b
+    lib.simdpackwithoutmaskd1(100, p(x), p(raw) + 1, b)
+    assert np.array_equal(raw[1:1 + 16 * b], orc.simdpackwithoutmaskd1(100, x, b))
+    xs = np.zeros(129, np.uint32)[1:]  # 4-byte aligned, not 16
+    out = np.zeros(129, np.uint32)[1:]
+    lib.simdunpackd1(100, p(raw) + 1, p(out), int(raw[0]))
+    assert np.array_equal(out, x)
+
+
+def test_example_c_stream_round_trip(lib, orc):
+    """compress() / decode loop of example.c:56-75,101-110 through the host API."""
+    nblk = 20
+    x = synth.sorted_gaps(6, nblk * 128, 9, first=0)
+    stream = np.zeros(nblk * (1 + 512), np.uint8)
+    pos, offset = 0, 0
+    for k in range(nblk):
+        blk = x[k * 128:(k + 1) * 128].copy()
+        b = lib.simdmaxbitsd1(offset, p(blk))
+        stream[pos] = b
+        pos += 1
+        lib.simdpackwithoutmaskd1(offset, p(blk), p(stream) + pos, b)
+        offset = int(blk[127])
+        pos += 16 * b
+    back = np.zeros(128, np.uint32)
+    rp, offset = 0, 0
+    for k in range(nblk):
+        b = int(stream[rp])
+        rp += 1
+        lib.simdunpackd1(offset, p(stream) + rp, p(back), b)
+        assert np.array_equal(back, x[k * 128:(k + 1) * 128])
+        rp += 16 * b
+        offset = int(back[127])
+    assert rp == pos
+
+
+@pytest.mark.parametrize("bit", [0, 1, 3, 7, 8, 13, 16, 21, 31, 32])
+def test_lengths(lib, orc, bit):
+    """issue21 / testshortpack / testlongpack / testshortFORpack of tests/unit.c, with oracle comparison."""
+    data = {"inrange": synth.random_bits(7, 3000, bit), "wild": synth.rand_u32(8, 3000)}
+    for name, full in data.items():
+        for n in [0, 1, 2, 3, 4, 5, 31, 127, 128, 129, 255, 257, 1000, 2047, 3000]:
+            x = full[:n].copy() if n else np.zeros(4, np.uint32)[:0]
+            xs = np.concatenate([x, np.zeros(4, np.uint32)])
+            nbytes = lib.simdpack_compressedbytes(n, bit)
+            buf = np.full(nbytes + 64, 0xA5, np.uint8)
+            end = lib.simdpack_length(p(xs), n, p(buf), bit)
+            assert end - p(buf) == nbytes, "returned pointer != compressedbytes"
+            assert np.array_equal(buf[:nbytes], orc.simdpack_length(x, bit)), ("simdpack_length", name, n, bit)
+            assert (buf[nbytes:] == 0xA5).all()
+            out = np.full(n + 8, 0xDEADBEEF, np.uint32)
+            rend = lib.simdunpack_length(p(buf), n, p(out), bit)
+            assert rend - p(buf) == (nbytes if n else 0)
+            want, _ = orc.simdunpack_length(buf[:nbytes], n, bit)
+            assert np.array_equal(out[:n], want) and (out[n:] == 0xDEADBEEF).all()
+            if name == "inrange":
+                assert np.array_equal(out[:n], x)
+            base = 7 if name == "inrange" else 0x9E3779B9
+            xf = (xs + np.uint32(base)).astype(np.uint32) if name == "inrange" else xs
+            buf = np.full(nbytes + 64, 0xA5, np.uint8)
+            end = lib.simdpackFOR_length(base, p(xf), n, p(buf), bit)
+            assert end - p(buf) == lib.simdpackFOR_compressedbytes(n, bit) == nbytes
+            assert np.array_equal(buf[:nbytes], orc.simdpackFOR_length(base, xf[:n].copy(), bit)), \
+                ("simdpackFOR_length", name, n, bit)
+            assert (buf[nbytes:] == 0xA5).all()
+            out = np.full(n + 8, 0xDEADBEEF, np.uint32)
+            lib.simdunpackFOR_length(base, p(buf), n, p(out), bit)
+            want, _ = orc.simdunpackFOR_length(base, buf[:nbytes], n, bit)
+            assert np.array_equal(out[:n], want) and (out[n:] == 0xDEADBEEF).all()
+            if n <= 128:
+                buf = np.full(nbytes + 64, 0xA5, np.uint8)
+                end = lib.simdpack_shortlength(p(xs), n, p(buf), bit)
+                assert end - p(buf) == nbytes
+                assert np.array_equal(buf[:nbytes], orc.simdpack_shortlength(x, bit)), ("short", name, n, bit)
+                out = np.full(n + 8, 0xDEADBEEF, np.uint32)
+                lib.simdunpack_shortlength(p(buf), n, p(out), bit)
+                want, _ = orc.simdunpack_shortlength(buf[:nbytes], n, bit)
+                assert np.array_equal(out[:n], want) and (out[n:] == 0xDEADBEEF).all()
+            assert lib.maxbits_length(p(xs), n) == orc.maxbits_length(xs, n)
+            assert lib.simdmin_length(p(xs), n) == orc.simdmin_length(xs, n)
+            lo, hi = C.c_uint32(), C.c_uint32()
+            lib.simdmaxmin_length(p(xs), n, C.byref(lo), C.byref(hi))
+            assert (lo.value, hi.value) == orc.simdmaxmin_length(xs, n)
+            if n:
+                assert lib.simdmaxbitsd1_length(9, p(xs), n) == orc.simdmaxbitsd1_length(9, xs, n)
+
+
+def test_long_array_crosses_pipeline_pieces(lib, orc):
+    """More than one 2^24-integer staging piece, ragged end, arbitrary 32-bit data
+    (so the frame packer's hand-over between blocks is exercised across the piece cut)."""
+    n = (1 << 24) + (1 << 18) + 77
+    x = synth.rand_u32(9, n)
+    for bit in (5, 32):
+        nbytes = lib.simdpack_compressedbytes(n, bit)
+        buf = np.zeros(nbytes + 16, np.uint8)
+        end = lib.simdpackFOR_length(12345, p(x), n, p(buf), bit)
+        assert end - p(buf) == nbytes
+        want = orc.simdpackFOR_length(12345, x, bit)
+        assert orc.fnv1a64(buf[:nbytes]) == orc.fnv1a64(want)
+        out = np.zeros(n, np.uint32)
+        lib.simdunpackFOR_length(12345, p(buf), n, p(out), bit)
+        wdec, _ = orc.simdunpackFOR_length(12345, want, n, bit)
+        assert orc.fnv1a64(out) == orc.fnv1a64(wdec)
+        end = lib.simdpack_length(p(x), n, p(buf), bit)
+        assert end - p(buf) == nbytes
+        assert orc.fnv1a64(buf[:nbytes]) == orc.fnv1a64(orc.simdpack_length(x, bit))
+    assert lib.maxbits_length(p(x), n) == 32
+    assert lib.simdmaxbitsd1_length(0, p(x), n) == 32
+
+
+def test_device_checksum_matches_host_formula():
+    import torch
+
+    from simdcomp_amd import codec
+
+    x = synth.rand_u32(70, 100000)
+    idx = (np.arange(len(x), dtype=np.uint64) + np.uint64(12345)) << np.uint64(32)
+    want = int(synth.splitmix64(idx ^ x.astype(np.uint64)).sum(dtype=np.uint64))
+    acc = codec.checksum(torch.from_numpy(x.view(np.int32)).cuda(), index0=12345)
+    assert int(acc[0].item()) & (2 ** 64 - 1) == want
