@@ -34,6 +34,39 @@ def timeit(fn, reps):
     return best
 
 
+def mixed(n, nblk, ints, out, reps):
+    """Mixed-width d1 stream (widths 1..20 skewed small, the example.c convention):
+    width reduction, offset scan, pack, unpack."""
+    dev = ints.device
+    widths = torch.minimum(torch.randint(1, 21, (nblk,), device=dev), torch.randint(1, 21, (nblk,), device=dev))
+    gaps = torch.randint(0, 2 ** 31 - 1, (n,), dtype=torch.int32, device=dev)
+    gaps &= ((1 << widths.to(torch.int64)) - 1).to(torch.int32).repeat_interleave(128)
+    ids = torch.cumsum(gaps, 0, dtype=torch.int32)
+    del gaps
+    seeds = torch.empty(nblk, dtype=torch.int32, device=dev)
+    bits = codec.maxbitsd1(ids, initvalue=0, initvalues_out=seeds)
+    off, total = codec.payload_offsets(bits)
+    nbytes = int(total.item())
+    payload = torch.empty(nbytes + 16, dtype=torch.uint8, device=dev)
+    codec.pack_mixed(1, ids, bits, off, payload, initvalues=seeds)
+    codec.unpack_mixed(1, payload, bits, off, nblk, initvalues=seeds, out=out)
+    assert torch.equal(out, ids)
+    extra = nblk * (4 + 1 + 8)
+    rows = {
+        "maxbitsd1": (lambda: codec.maxbitsd1(ids, initvalue=0, initvalues_out=seeds), nblk * (512 + 5)),
+        "payload_offsets": (lambda: codec.payload_offsets(bits), nblk * 9),
+        "pack_mixed": (lambda: codec.pack_mixed(1, ids, bits, off, payload, initvalues=seeds), nblk * 512 + nbytes + extra),
+        "unpack_mixed": (lambda: codec.unpack_mixed(1, payload, bits, off, nblk, initvalues=seeds, out=out),
+                         nblk * 512 + nbytes + extra),
+    }
+    res = {"avg_bits": round(nbytes / nblk / 16, 2)}
+    for name, (f, by) in rows.items():
+        t = timeit(f, reps)
+        res[name] = {"ms": round(t * 1e3, 4), "Gint/s": round(n / t / 1e9, 1), "GB/s": round(by / t / 1e9, 1),
+                     "frac": round(by / t / PEAK, 3)}
+    print("mixed", json.dumps(res), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--log2n", type=int, default=28)
@@ -59,6 +92,8 @@ def main():
             t = timeit(lambda: ints.sum(), a.reps)
             res["read(sum)"] = {"GB/s": 4 * n / t / 1e9}
             print(json.dumps(res), flush=True)
+            continue
+        if what == "mixed":
             continue
         row = {}
         for b in bits:
@@ -88,6 +123,8 @@ def main():
                 break
         res[what] = row
         print(what, json.dumps(row), flush=True)
+    if "mixed" in a.what.split(","):
+        mixed(n, nblk, ints, out, a.reps)
 
 
 if __name__ == "__main__":
