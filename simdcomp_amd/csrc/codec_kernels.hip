@@ -893,9 +893,10 @@ constexpr int REDUCE_U = 4;
 // store traffic and need two blocks per half-wave to cover the payload read
 // behind them; from 13 bits up one block per half-wave measured fastest.  The
 // per-block-width kernels chase two dependent loads (offset, then payload) and
-// measured best with four.
+// measured best with four.  The encoders read 512 bytes per block whatever the
+// width; they measured best with one step from 8 bits up.
 constexpr int unpack_steps(int b) { return b < 0 ? 4 : (b <= 12 ? 2 : 1); }
-constexpr int pack_steps(int b) { return b < 0 ? 4 : (b <= 12 ? 2 : 1); }
+constexpr int pack_steps(int b) { return b < 0 ? 4 : (b == 3 ? 4 : (b <= 7 ? 2 : 1)); }
 
 // index 0 is the per-block-width instance (B = -1), index 1 + b the uniform width b
 template <int MODE, int BP1>
