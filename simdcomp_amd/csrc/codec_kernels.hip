@@ -397,14 +397,14 @@ __global__ __launch_bounds__(256) void k_pack_flex(PackArgs a) {
 //   widths a.bits[] and payload offsets a.off[].  a.seeds[] must be an array
 //   for the d1 / FOR modes.  Launch with grid = nblocks / (8*U) workgroups.
 
-template <int B, int MODE, int U>
-__global__ __launch_bounds__(256) void k_unpack_fast(UnpackArgs a) {
-  __shared__ u32x4 lds[4][2][33];
+template <int B, int MODE, int U, int BS>
+__global__ __launch_bounds__(BS) void k_unpack_fast(UnpackArgs a) {
+  __shared__ u32x4 lds[BS / 64][2][33];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int h = lane >> 5, k = lane & 31;
   u32x4 *slot = lds[wv][h];
   const u32x4 *payload = reinterpret_cast<const u32x4 *>(a.payload);
-  constexpr size_t per_iter = (size_t)BLOCKS_PER_STEP * U;
+  constexpr size_t per_iter = (size_t)(BS / 32) * U;
 
   {
     const size_t tile = blockIdx.x;
@@ -549,12 +549,12 @@ __device__ __forceinline__ void unpack_finish(const u32x4 ld, const uint32_t b, 
   else stream_store(reinterpret_cast<u32x4 *>(out_row), v);
 }
 
-template <int B, int MODE, bool MASKED, int U>
-__global__ __launch_bounds__(256) void k_pack_fast(PackArgs a) {
+template <int B, int MODE, bool MASKED, int U, int BS>
+__global__ __launch_bounds__(BS) void k_pack_fast(PackArgs a) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int h = lane >> 5, k = lane & 31;
   u32x4 *payload = reinterpret_cast<u32x4 *>(a.payload);
-  constexpr size_t per_iter = (size_t)BLOCKS_PER_STEP * U;
+  constexpr size_t per_iter = (size_t)(BS / 32) * U;
 
   {
     const size_t tile = blockIdx.x;
@@ -889,22 +889,26 @@ static int grid_for(size_t nblocks, int U) {
 constexpr int FLEX_U = 2;
 constexpr int REDUCE_U = 4;
 
-// Steps per workgroup for the one-shot kernels.  Narrow widths are almost pure
-// store traffic and need two blocks per half-wave to cover the payload read
-// behind them; from 13 bits up one block per half-wave measured fastest.  The
-// per-block-width kernels chase two dependent loads (offset, then payload) and
-// measured best with four.  The encoders read 512 bytes per block whatever the
-// width; they measured best with one step from 8 bits up.
-constexpr int unpack_steps(int b) { return b < 0 ? 4 : (b <= 12 ? 2 : 1); }
+// Workgroup shape of the one-shot decoders, from a sweep of (threads, steps)
+// at every width with 2^30 integers: the best shapes write 4 KiB (narrow
+// widths, which are almost pure store traffic and need two blocks per half-wave
+// to cover the payload read in front of the stores) or 2 KiB per workgroup;
+// very wide blocks prefer 256 threads.  The per-block-width kernels chase two
+// dependent loads (offset, then payload) and measured best with four steps.
+constexpr int unpack_threads(int b) { return (b < 0 || b >= 28) ? 256 : 128; }
+constexpr int unpack_steps(int b) { return b < 0 ? 4 : (b <= 14 ? 2 : 1); }
+// The encoders read 512 bytes per block whatever the width.
+constexpr int pack_threads(int b) { return (b > 0 && b <= 7 && b != 3) ? 128 : 256; }
 constexpr int pack_steps(int b) { return b < 0 ? 4 : (b == 3 ? 4 : (b <= 7 ? 2 : 1)); }
 
 // index 0 is the per-block-width instance (B = -1), index 1 + b the uniform width b
 template <int MODE, int BP1>
 static size_t launch_unpack_fast(const UnpackArgs &a, hipStream_t st) {
-  constexpr int U = unpack_steps(BP1 - 1);
-  const size_t nwg = a.nblocks / (BLOCKS_PER_STEP * U);
-  if (nwg) hipLaunchKernelGGL((k_unpack_fast<BP1 - 1, MODE, U>), dim3((unsigned)nwg), dim3(256), 0, st, a);
-  return nwg * BLOCKS_PER_STEP * U;
+  constexpr int U = unpack_steps(BP1 - 1), BS = unpack_threads(BP1 - 1);
+  constexpr size_t per_wg = (size_t)(BS / 32) * U;
+  const size_t nwg = a.nblocks / per_wg;
+  if (nwg) hipLaunchKernelGGL((k_unpack_fast<BP1 - 1, MODE, U, BS>), dim3((unsigned)nwg), dim3(BS), 0, st, a);
+  return nwg * per_wg;
 }
 
 template <int MODE, int... Is>
@@ -967,10 +971,11 @@ hipError_t launch_unpack(int mode, bool tail, const UnpackArgs &a, hipStream_t s
 
 template <int MODE, bool MASKED, int BP1>
 static size_t launch_pack_fast(const PackArgs &a, hipStream_t st) {
-  constexpr int U = pack_steps(BP1 - 1);
-  const size_t nwg = a.nblocks / (BLOCKS_PER_STEP * U);
-  if (nwg) hipLaunchKernelGGL((k_pack_fast<BP1 - 1, MODE, MASKED, U>), dim3((unsigned)nwg), dim3(256), 0, st, a);
-  return nwg * BLOCKS_PER_STEP * U;
+  constexpr int U = pack_steps(BP1 - 1), BS = pack_threads(BP1 - 1);
+  constexpr size_t per_wg = (size_t)(BS / 32) * U;
+  const size_t nwg = a.nblocks / per_wg;
+  if (nwg) hipLaunchKernelGGL((k_pack_fast<BP1 - 1, MODE, MASKED, U, BS>), dim3((unsigned)nwg), dim3(BS), 0, st, a);
+  return nwg * per_wg;
 }
 
 template <int MODE, bool MASKED, int... Is>

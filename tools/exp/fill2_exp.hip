@@ -14,6 +14,22 @@ __global__ __launch_bounds__(BS) void fill_wave(u32x4 *out, uint32_t val) {
 #pragma unroll
   for (int j = 0; j < CH; ++j) o[j * 64] = u32x4{val, val, val, val};
 }
+template <int CH, int BS>
+__global__ __launch_bounds__(BS) void fill_wave_nt(u32x4 *out, uint32_t val) {
+  const size_t wave = (size_t)blockIdx.x * (BS / 64) + (threadIdx.x >> 6);
+  u32x4 *o = out + wave * 64 * CH + (threadIdx.x & 63);
+#pragma unroll
+  for (int j = 0; j < CH; ++j) __builtin_nontemporal_store(u32x4{val, val, val, val}, &o[j * 64]);
+}
+template <int CH, bool DRAIN>
+__global__ __launch_bounds__(256) void fill_wave_gs_nt(u32x4 *out, size_t nwavechunks, uint32_t val) {
+  for (size_t c = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); c < nwavechunks; c += (size_t)gridDim.x * 4) {
+    u32x4 *o = out + c * 64 * CH + (threadIdx.x & 63);
+#pragma unroll
+    for (int j = 0; j < CH; ++j) __builtin_nontemporal_store(u32x4{val, val, val, val}, &o[j * 64]);
+    if (DRAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+}
 // same with a dependent load: DEP=1 -> 16 B per half-wave at "payload of block" address (b=1 pattern, HBM),
 // DEP=2 -> everyone reads the same 1 KiB (cache resident)
 template <int CH, int BS, int DEP>
@@ -64,6 +80,14 @@ template <int CH, int BS> static void t_fill() {
   char nm[64]; snprintf(nm, 64, "fill_wave CH=%d BS=%d", CH, BS);
   RUN(nm, hipLaunchKernelGGL((fill_wave<CH, BS>), dim3(nvec / (BS * CH)), dim3(BS), 0, 0, out, 7u));
 }
+template <int CH, int BS> static void t_fill_nt() {
+  char nm[64]; snprintf(nm, 64, "fill_wave_nt CH=%d BS=%d", CH, BS);
+  RUN(nm, hipLaunchKernelGGL((fill_wave_nt<CH, BS>), dim3(nvec / (BS * CH)), dim3(BS), 0, 0, out, 7u));
+}
+template <int CH, bool DRAIN> static void t_gs_nt(int g) {
+  char nm[64]; snprintf(nm, 64, "fill_wave_gs_nt CH=%d drain=%d grid=%d", CH, (int)DRAIN, g);
+  RUN(nm, hipLaunchKernelGGL((fill_wave_gs_nt<CH, DRAIN>), dim3(g), dim3(256), 0, 0, out, nvec / (64 * CH), 7u));
+}
 template <int CH, int BS, int DEP> static void t_dep() {
   char nm[64]; snprintf(nm, 64, "fill_wave_dep CH=%d BS=%d DEP=%d", CH, BS, DEP);
   RUN(nm, hipLaunchKernelGGL((fill_wave_dep<CH, BS, DEP>), dim3(nvec / (BS * CH)), dim3(BS), 0, 0, in, out));
@@ -80,14 +104,8 @@ int main(int argc, char **argv) {
   CK(hipMalloc(&out, n * 4)); CK(hipMalloc(&in, n * 4)); CK(hipMalloc(&sink, 64));
   CK(hipMemset(in, 0x5b, n * 4));
   gb = n * 4.0 / 1e6;
-  t_fill<1, 64>(); t_fill<2, 64>(); t_fill<4, 64>(); t_fill<8, 64>(); t_fill<16, 64>();
-  t_fill<1, 128>(); t_fill<2, 128>(); t_fill<4, 128>();
-  t_fill<1, 256>(); t_fill<2, 256>(); t_fill<4, 256>(); t_fill<8, 256>(); t_fill<16, 256>();
-  t_fill<1, 1024>(); t_fill<4, 1024>();
-  t_dep<1, 64, 1>(); t_dep<2, 64, 1>(); t_dep<4, 64, 1>(); t_dep<8, 64, 1>();
-  t_dep<1, 256, 1>(); t_dep<2, 256, 1>(); t_dep<4, 256, 1>(); t_dep<8, 256, 1>();
-  t_dep<1, 64, 2>(); t_dep<2, 64, 2>(); t_dep<4, 64, 2>();
-  t_dep<1, 256, 2>(); t_dep<2, 256, 2>(); t_dep<4, 256, 2>();
-  for (int g : {1024, 2048, 4096}) { t_gs<1, false>(g); t_gs<1, true>(g); t_gs<4, false>(g); t_gs<4, true>(g); }
+  t_fill<1, 256>(); t_fill<2, 256>(); t_fill<4, 256>();
+  t_fill_nt<1, 256>(); t_fill_nt<2, 256>(); t_fill_nt<4, 256>(); t_fill_nt<2, 128>(); t_fill_nt<1, 512>();
+  for (int g : {256, 512, 1024, 2048}) { t_gs<1, true>(g); t_gs_nt<1, true>(g); t_gs_nt<1, false>(g); t_gs_nt<2, true>(g); t_gs_nt<4, true>(g); }
   return 0;
 }
