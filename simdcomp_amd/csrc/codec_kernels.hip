@@ -397,8 +397,31 @@ __global__ __launch_bounds__(256) void k_pack_flex(PackArgs a) {
 //   widths a.bits[] and payload offsets a.off[].  a.seeds[] must be an array
 //   for the d1 / FOR modes.  Launch with grid = nblocks / (8*U) workgroups.
 
-template <int B, int MODE, int U, int BS>
-__global__ __launch_bounds__(BS) void k_unpack_fast(UnpackArgs a) {
+//  3. With so little in flight per wave, a wave's lifetime is what limits the
+//     narrow widths: its payload read waits on HBM behind the chip's store
+//     traffic before the stores can even be issued.  When PF > 0 every PF decode
+//     workgroups are preceded in the grid by one workgroup that only touches
+//     the payload (and seeds) of the group `dist` groups further on, so the
+//     decode waves find their input in the memory-side cache.  The prefetching
+//     waves do wait on HBM, but they are 1 in PF + 1.  (Issuing the same
+//     prefetch from the decode waves themselves gains nothing: a wave keeps
+//     its slot until its last load has returned.)
+
+// Touch NV consecutive 16-byte vectors of p starting at v0 with ordinary (cache-allocating) loads, all issued
+// back to back; indices past `last` re-read `last`.
+template <int BS, int NV>
+__device__ __forceinline__ void touch_vectors(const u32x4 *p, size_t v0, size_t last, u32x4 &acc) {
+  constexpr int TRIPS = (NV + BS - 1) / BS;
+#pragma unroll
+  for (int t = 0; t < TRIPS; ++t) {
+    size_t v = v0 + (size_t)t * BS + threadIdx.x;
+    v = v < last ? v : last;
+    acc |= p[v];
+  }
+}
+
+template <int B, int MODE, int U, int BS, int PF = 0>
+__global__ __launch_bounds__(BS) void k_unpack_fast(UnpackArgs a, uint32_t nwg = 0, uint32_t dist = 0) {
   __shared__ u32x4 lds[BS / 64][2][33];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int h = lane >> 5, k = lane & 31;
@@ -406,8 +429,30 @@ __global__ __launch_bounds__(BS) void k_unpack_fast(UnpackArgs a) {
   const u32x4 *payload = reinterpret_cast<const u32x4 *>(a.payload);
   constexpr size_t per_iter = (size_t)(BS / 32) * U;
 
+  size_t tile = blockIdx.x;
+  if constexpr (PF > 0) {
+    static_assert(B > 0, "prefetch groups are for uniform widths");
+    const uint32_t group = blockIdx.x / (PF + 1), r = blockIdx.x - group * (PF + 1);
+    if (r == 0) {
+      // groups [t0, t1): two per prefetcher while the distance ramps up from the start of the array, one after
+      const size_t t0 = (size_t)group + (group + 1 < dist ? group + 1 : dist);
+      const size_t t1 = (size_t)group + 1 + (group + 2 < dist ? group + 2 : dist);
+      constexpr size_t GB = (size_t)PF * per_iter;
+      const size_t nblk = (size_t)nwg * per_iter;
+      u32x4 acc = {0, 0, 0, 0};
+      for (size_t t = t0; t < t1; ++t) {
+        if (t * GB >= nblk) break;
+        touch_vectors<BS, (int)GB * B>(payload, t * GB * B, nblk * B - 1, acc);
+        if constexpr (MODE != MODE_PLAIN)  // 4 seeds per vector; per_iter is a multiple of 4
+          touch_vectors<BS, (int)GB / 4>(reinterpret_cast<const u32x4 *>(a.seeds), t * GB / 4, nblk / 4 - 1, acc);
+      }
+      asm volatile("" ::"v"(acc));  // keeps the loads; the only wait of this workgroup
+      return;
+    }
+    tile = (size_t)group * PF + (r - 1);
+    if (tile >= nwg) return;
+  }
   {
-    const size_t tile = blockIdx.x;
     const size_t first = tile * per_iter + (size_t)wv * 2 * U + h;
     uint32_t b[U], seed[U];
     const u32x4 *src[U];
@@ -897,6 +942,13 @@ constexpr int REDUCE_U = 4;
 // dependent loads (offset, then payload) and measured best with four steps.
 constexpr int unpack_threads(int b) { return (b < 0 || b >= 28) ? 256 : 128; }
 constexpr int unpack_steps(int b) { return b < 0 ? 4 : (b <= 14 ? 2 : 1); }
+// Widths 1..7 gain 3-17 points of HBM peak from dedicated prefetch workgroups
+// (one per 16 decode workgroups, 20 MiB of output ahead: the plateau of a
+// sweep over group size 8..512 and distance 4..64 MiB); from 8 bits on the
+// payload is a large enough share of the traffic that the extra reads cost
+// more than the latency they hide.
+constexpr int unpack_prefetch_group(int b) { return (b >= 1 && b <= 7) ? 16 : 0; }
+constexpr size_t PREFETCH_DISTANCE_BYTES = (size_t)20 << 20;
 // The encoders read 512 bytes per block whatever the width.
 constexpr int pack_threads(int b) { return (b > 0 && b <= 7 && b != 3) ? 128 : 256; }
 constexpr int pack_steps(int b) { return b < 0 ? 4 : (b == 3 ? 4 : (b <= 7 ? 2 : 1)); }
@@ -904,10 +956,18 @@ constexpr int pack_steps(int b) { return b < 0 ? 4 : (b == 3 ? 4 : (b <= 7 ? 2 :
 // index 0 is the per-block-width instance (B = -1), index 1 + b the uniform width b
 template <int MODE, int BP1>
 static size_t launch_unpack_fast(const UnpackArgs &a, hipStream_t st) {
-  constexpr int U = unpack_steps(BP1 - 1), BS = unpack_threads(BP1 - 1);
+  constexpr int U = unpack_steps(BP1 - 1), BS = unpack_threads(BP1 - 1), PF = unpack_prefetch_group(BP1 - 1);
   constexpr size_t per_wg = (size_t)(BS / 32) * U;
   const size_t nwg = a.nblocks / per_wg;
-  if (nwg) hipLaunchKernelGGL((k_unpack_fast<BP1 - 1, MODE, U, BS>), dim3((unsigned)nwg), dim3(BS), 0, st, a);
+  if (nwg == 0) return 0;
+  if constexpr (PF > 0) {
+    const size_t groups = (nwg + PF - 1) / PF;
+    const size_t dist = PREFETCH_DISTANCE_BYTES / (PF * per_wg * 512);
+    hipLaunchKernelGGL((k_unpack_fast<BP1 - 1, MODE, U, BS, PF>), dim3((unsigned)(groups * (PF + 1))), dim3(BS), 0, st, a,
+                       (uint32_t)nwg, (uint32_t)dist);
+  } else {
+    hipLaunchKernelGGL((k_unpack_fast<BP1 - 1, MODE, U, BS, 0>), dim3((unsigned)nwg), dim3(BS), 0, st, a, 0u, 0u);
+  }
   return nwg * per_wg;
 }
 

@@ -112,6 +112,30 @@ def test_ragged_block_counts(dev, orc, nblk):
         assert (got[nblk * 128:] == 0x5A5A5A5A).all(), "unpack wrote past its output"
 
 
+def test_long_arrays_narrow_widths(dev, orc):
+    """Narrow widths interleave prefetch workgroups with the decoding ones; an
+    array long enough to leave the start-up ramp of the prefetch distance, with a
+    block count that is no multiple of the group size."""
+    nblk = 8 * 16 * 700 + 8 * 5 + 3
+    for mode, bit in (("d1", 1), ("d1", 3), ("d1", 7), ("plain", 2), ("for", 5), ("d1", 8)):
+        if mode == "d1":
+            x = synth.sorted_gaps(70 + bit, nblk * 128, bit, first=3)
+            seeds = synth.block_offsets(x, 3)
+            payload = dev.packd1(to_dev(x), bit, initvalues=to_dev(seeds))
+            dec = dev.unpackd1(to_dev(seeds), payload, nblk, bit)
+        elif mode == "plain":
+            x, seeds = synth.random_bits(71, nblk * 128, bit), None
+            payload = dev.pack(to_dev(x), bit)
+            dec = dev.unpack(payload, nblk, bit)
+        else:
+            x, seeds = synth.clustered(72, nblk, bit)
+            payload = dev.packFOR(to_dev(seeds), to_dev(x), bit)
+            dec = dev.unpackFOR(to_dev(seeds), payload, nblk, bit)
+        want = orc.batch_pack(mode, x, bit, seeds=seeds)
+        assert np.array_equal(to_np(payload), want), (mode, bit)
+        assert np.array_equal(to_np(dec), x), (mode, bit)
+
+
 def test_reductions(dev, orc):
     for bit in BITS:
         x = synth.sorted_gaps(40 + bit, NBLK * 128, bit, first=77)
