@@ -407,16 +407,19 @@ __global__ __launch_bounds__(256) void k_pack_flex(PackArgs a) {
 //     prefetch from the decode waves themselves gains nothing: a wave keeps
 //     its slot until its last load has returned.)
 
-// Touch NV consecutive 16-byte vectors of p starting at v0 with ordinary (cache-allocating) loads, all issued
-// back to back; indices past `last` re-read `last`.
-template <int BS, int NV>
-__device__ __forceinline__ void touch_vectors(const u32x4 *p, size_t v0, size_t last, u32x4 &acc) {
+// Touch the 16-byte vectors that hold bytes [byte0, byte0 + NBYTES) of `base` with ordinary (cache-allocating)
+// loads, all issued back to back; vectors past the one holding `last_byte` re-read that one.  `base` needs no
+// alignment: addresses are rounded down to 16, which stays inside the 16-byte chunk the array starts in.
+template <int BS, size_t NBYTES>
+__device__ __forceinline__ void touch_bytes(const void *base, size_t byte0, size_t last_byte, u32x4 &acc) {
+  constexpr int NV = (int)(NBYTES / 16) + 1;  // + 1: an unaligned range straddles one more vector
   constexpr int TRIPS = (NV + BS - 1) / BS;
+  const uintptr_t v0 = ((uintptr_t)base + byte0) >> 4, vlast = ((uintptr_t)base + last_byte) >> 4;
 #pragma unroll
   for (int t = 0; t < TRIPS; ++t) {
-    size_t v = v0 + (size_t)t * BS + threadIdx.x;
-    v = v < last ? v : last;
-    acc |= p[v];
+    uintptr_t v = v0 + (uintptr_t)t * BS + threadIdx.x;
+    v = v < vlast ? v : vlast;
+    acc |= *reinterpret_cast<const u32x4 *>(v << 4);
   }
 }
 
@@ -442,9 +445,8 @@ __global__ __launch_bounds__(BS) void k_unpack_fast(UnpackArgs a, uint32_t nwg =
       u32x4 acc = {0, 0, 0, 0};
       for (size_t t = t0; t < t1; ++t) {
         if (t * GB >= nblk) break;
-        touch_vectors<BS, (int)GB * B>(payload, t * GB * B, nblk * B - 1, acc);
-        if constexpr (MODE != MODE_PLAIN)  // 4 seeds per vector; per_iter is a multiple of 4
-          touch_vectors<BS, (int)GB / 4>(reinterpret_cast<const u32x4 *>(a.seeds), t * GB / 4, nblk / 4 - 1, acc);
+        touch_bytes<BS, GB * B * 16>(a.payload, t * GB * B * 16, nblk * B * 16 - 1, acc);
+        if constexpr (MODE != MODE_PLAIN) touch_bytes<BS, GB * 4>(a.seeds, t * GB * 4, nblk * 4 - 1, acc);
       }
       asm volatile("" ::"v"(acc));  // keeps the loads; the only wait of this workgroup
       return;
@@ -946,7 +948,9 @@ constexpr int unpack_steps(int b) { return b < 0 ? 4 : (b <= 14 ? 2 : 1); }
 // (one per 16 decode workgroups, 20 MiB of output ahead: the plateau of a
 // sweep over group size 8..512 and distance 4..64 MiB); from 8 bits on the
 // payload is a large enough share of the traffic that the extra reads cost
-// more than the latency they hide.
+// more than the latency they hide.  The per-block-width decoder does not gain
+// either: its prefetcher has to chase offsets itself and its scattered touches
+// cost more than they save.
 constexpr int unpack_prefetch_group(int b) { return (b >= 1 && b <= 7) ? 16 : 0; }
 constexpr size_t PREFETCH_DISTANCE_BYTES = (size_t)20 << 20;
 // The encoders read 512 bytes per block whatever the width.

@@ -73,6 +73,71 @@ __global__ __launch_bounds__(BS) void k_shot_pfd(UnpackArgs a, int dist) {
   }
 }
 
+// XCD-aware variant: workgroup id % 8 is the XCD (and L2) a workgroup lands on.  A group is 8 prefetch workgroups
+// followed by PG decode workgroups (PG % 8 == 0); prefetcher x touches the payload of the decode workgroups of the
+// target group that will run on XCD x, so the lines wait in the L2 that will use them.
+template <int B, int MODE, int U, int BS, int PG>
+__global__ __launch_bounds__(BS) void k_shot_pfx(UnpackArgs a, uint32_t dist) {
+  __shared__ u32x4 lds[BS / 64][2][33];
+  constexpr int PER_WG = (BS / 32) * U;
+  static_assert(PG % 8 == 0, "PG");
+  const u32x4 *payload = reinterpret_cast<const u32x4 *>(a.payload);
+  const uint32_t group = blockIdx.x / (PG + 8), r = blockIdx.x % (PG + 8);
+  if (r < 8) {
+    const size_t t = (size_t)group + dist;
+    constexpr int VPW = PER_WG * B;            // payload vectors per decode workgroup
+    constexpr int NV = (PG / 8) * VPW;         // vectors this prefetcher touches
+    constexpr int TRIPS = (NV + BS - 1) / BS;
+    const size_t lastv = a.nblocks * (size_t)B - 1;
+    u32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+    for (int tr = 0; tr < TRIPS; ++tr) {
+      const uint32_t f = tr * BS + threadIdx.x;
+      const uint32_t i = f / VPW, within = f % VPW;
+      size_t v = (t * PG + r + 8 * (size_t)i) * VPW + within;
+      v = v < lastv ? v : lastv;
+      acc |= payload[v];
+    }
+    if constexpr (MODE != MODE_PLAIN) {
+      // seeds: PER_WG * 4 bytes per decode workgroup; one 16-byte vector covers 4 blocks
+      constexpr int SVPW = PER_WG / 4;
+      constexpr int SNV = (PG / 8) * SVPW;
+      constexpr int STRIPS = (SNV + BS - 1) / BS;
+      const u32x4 *sp = reinterpret_cast<const u32x4 *>(a.seeds);
+      const size_t lasts = a.nblocks / 4 - 1;
+#pragma unroll
+      for (int tr = 0; tr < STRIPS; ++tr) {
+        const uint32_t f = tr * BS + threadIdx.x;
+        const uint32_t i = f / SVPW, within = f % SVPW;
+        size_t v = (t * PG + r + 8 * (size_t)i) * SVPW + within;
+        v = v < lasts ? v : lasts;
+        acc |= sp[v];
+      }
+    }
+    asm volatile("" ::"v"(acc));
+    return;
+  }
+  const size_t dg = (size_t)group * PG + (r - 8);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int h = lane >> 5, k = lane & 31;
+  u32x4 *slot = lds[wv][h];
+  const int kk = k < B ? k : (B ? B - 1 : 0);
+  const size_t first = (dg * (BS / 64) + wv) * 2 * U + h;
+  u32x4 rr[U];
+  uint32_t sd[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const size_t blk = first + 2 * (size_t)u;
+    rr[u] = payload[blk * (size_t)B + kk];
+    if constexpr (MODE != MODE_PLAIN) sd[u] = a.seeds[blk];
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const size_t blk = first + 2 * (size_t)u;
+    unpack_finish<B, MODE, 1>(rr[u], B, MODE != MODE_PLAIN ? sd[u] : 0u, slot, k, a.out + blk * 128 + 4 * k);
+  }
+}
+
 static size_t g_nblk;
 static UnpackArgs g_a;
 static uint8_t *g_region;
@@ -117,6 +182,26 @@ template <int B, int U, int BS, int P, int DIST, int SPARSE = 0> static void run
   fflush(stdout);
 }
 
+template <int B, int U, int BS, int PG> static void runx(int dist_mib) {
+  constexpr int PER_WG = (BS / 32) * U;
+  size_t nblk = g_nblk / ((size_t)PER_WG * PG) * ((size_t)PER_WG * PG);
+  size_t ngroups = nblk / ((size_t)PER_WG * PG);
+  size_t grid = ngroups * (PG + 8);
+  size_t slice = (nblk * 16 * (size_t)B + 4095) / 4096 * 4096;
+  uint32_t dist = (uint32_t)(((size_t)dist_mib << 20) / ((size_t)PER_WG * PG * 512));
+  if (dist < 1) dist = 1;
+  double ms = time_ms([&] {
+    UnpackArgs a = g_a; a.bit = B; a.nblocks = nblk;
+    if (g_cursor + slice > g_region_bytes) g_cursor = 0;
+    a.payload = g_region + g_cursor;
+    g_cursor += slice;
+    a.seeds = g_seed_region + (g_seed_i++ % g_seed_slices) * g_nblk;
+    hipLaunchKernelGGL((k_shot_pfx<B, MODE_D1, U, BS, PG>), dim3(grid), dim3(BS), 0, 0, a, dist);
+  });
+  double bytes = (double)nblk * (512 + 16 * B + 4);
+  printf("b=%2d xcd-aware PG=%3d distMiB=%2d (D=%3u)  %.4f ms %7.1f GB/s frac %.3f\n", B, PG, dist_mib, dist, ms, bytes / ms / 1e6, bytes / ms / 8e9);
+  fflush(stdout);
+}
 template <int B> static void prod() {
   size_t nblk = g_nblk;
   size_t slice = (nblk * 16 * (size_t)B + 4095) / 4096 * 4096;
@@ -126,16 +211,15 @@ template <int B> static void prod() {
     a.payload = g_region + g_cursor;
     g_cursor += slice;
     a.seeds = g_seed_region + (g_seed_i++ % g_seed_slices) * g_nblk;
-    launch_unpack(MODE_D1, false, a, 0);
+    (void)launch_unpack(MODE_D1, false, a, 0);
   });
   double bytes = (double)nblk * (512 + 16 * B + 4);
   printf("b=%2d production  %.4f ms %7.1f GB/s frac %.3f\n", B, ms, bytes / ms / 1e6, bytes / ms / 8e9);
 }
 template <int B, int U, int BS> static void sweep() {
-  run<B, U, BS, 16, 0>();
-  for (int mib : {12, 20, 32}) run<B, U, BS, 4, 1, 0>(mib);
-  for (int mib : {12, 20, 32}) run<B, U, BS, 8, 1, 0>(mib);
-  for (int mib : {12, 20, 32}) run<B, U, BS, 16, 1, 0>(mib);
+  prod<B>();
+  for (int mib : {2, 4, 8, 12, 20, 32}) runx<B, U, BS, 128>(mib);
+  for (int mib : {2, 4, 8, 12, 20, 32}) runx<B, U, BS, 64>(mib);
 }
 
 int main(int argc, char **argv) {
@@ -147,7 +231,6 @@ int main(int argc, char **argv) {
   CK(hipMalloc(&out, n * 4)); g_seed_slices = 24; CK(hipMalloc(&g_seed_region, g_seed_slices * g_nblk * 4)); seeds = g_seed_region; CK(hipMalloc(&g_region, g_region_bytes + 4096));
   CK(hipMemset(g_region, 0x5b, g_region_bytes)); CK(hipMemset(seeds, 1, g_seed_slices * g_nblk * 4));
   g_a = UnpackArgs{}; g_a.seeds = seeds; g_a.out = out; g_a.nblocks = g_nblk; g_a.length = n;
-  sweep<8, 2, 128>(); sweep<9, 2, 128>(); sweep<10, 2, 128>(); sweep<12, 2, 128>(); sweep<14, 2, 128>();
-  sweep<16, 1, 128>(); sweep<20, 1, 128>(); sweep<24, 1, 128>();
+  sweep<1, 2, 128>(); sweep<2, 2, 128>(); sweep<4, 2, 128>(); sweep<7, 2, 128>(); sweep<10, 2, 128>();
   return 0;
 }
