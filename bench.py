@@ -22,6 +22,8 @@ Extra objects on the JSON line:
   cpu_baseline  the reference's own simdunpackd1 (compiled from its sources
                 into oracle/_ref, SSE4.1) timed on this host on a bounded
                 sample, 1 thread (and all cores as `all_cores`);
+  encode        simdpackwithoutmaskd1 over the same corpus (rank 0's GPU, outside
+                the timed steps), output compared byte for byte with the payload;
   host_to_host  the same decode including pinned H2D/D2H copies (rank 0 only).
 """
 import argparse
@@ -49,11 +51,9 @@ def algorithmic_bytes(nblocks, b):
     return nblocks * (512 + 16 * b + 4)
 
 
-def build_corpus(nblocks, b, seed, dev):
+def make_ids(nblocks, b, seed, dev):
     """Sorted docIDs with random gaps below 2^b (the distribution of the
-    reference's d1 benchmark generator, benchmarks/bitpackingbenchmark.c:44-53),
-    encoded on the device.  Returns (payload, offsets, number of decode
-    mismatches, checksum of the decoded array)."""
+    reference's d1 benchmark generator, benchmarks/bitpackingbenchmark.c:44-53)."""
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
     n = nblocks * 128
@@ -62,14 +62,49 @@ def build_corpus(nblocks, b, seed, dev):
         gaps &= (1 << b) - 1
     elif b == 32:
         gaps = gaps * 2 + (gaps & 1)  # use all 32 bits
-    ids = torch.cumsum(gaps, 0, dtype=torch.int32)  # wraps mod 2^32 like the reference's uint32 sums
-    del gaps
+    return torch.cumsum(gaps, 0, dtype=torch.int32)  # wraps mod 2^32 like the reference's uint32 sums
+
+
+def build_corpus(nblocks, b, seed, dev):
+    """Encode the docIDs of make_ids on the device.  Returns (payload, offsets,
+    [checksum of the decoded array, number of decode mismatches])."""
+    ids = make_ids(nblocks, b, seed, dev)
     offsets = torch.empty(nblocks, dtype=torch.int32, device=dev)
     payload = codec.packd1(ids, b, initvalue=0, masked=False, initvalues_out=offsets)
     back = codec.unpackd1(offsets, payload, nblocks, b)
     acc = codec.checksum(back, other=ids)
     torch.cuda.synchronize()
     return payload, offsets, acc
+
+
+def encode_leg(corpora, nblocks, seed0, dev, reps=3):
+    """simdpackwithoutmaskd1 over the same corpus at every width (outside the
+    timed steps): regenerates the docIDs, times the encoder with HIP events and
+    checks its output byte for byte against the payload the decoder was fed."""
+    tot_bytes = tot_time = 0.0
+    table, wrong = {}, 0
+    for b in WIDTHS:
+        payload, offsets = corpora[b]
+        ids = make_ids(nblocks, b, seed0 + b, dev)
+        out = torch.empty_like(payload)
+        best = 1e9
+        for _ in range(reps + 1):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            codec.packd1(ids, b, initvalues=offsets, masked=False, out=out)
+            e1.record()
+            e1.synchronize()
+            best = min(best, e0.elapsed_time(e1) * 1e-3)
+        wrong += 0 if torch.equal(out, payload) else 1
+        nbytes = algorithmic_bytes(nblocks, b)
+        tot_bytes += nbytes
+        tot_time += best
+        table[str(b)] = {"ms": round(best * 1e3, 4), "frac": round(nbytes / best / HBM_PEAK, 4)}
+        del ids, out
+    return {"kernel": "sc::k_pack_fast<b, d1, unmasked>", "value": nblocks * 128 * len(WIDTHS) / tot_time, "unit": "int32/s per GPU",
+            "achieved_GB/s": round(tot_bytes / tot_time / 1e9, 1), "frac": round(tot_bytes / tot_time / HBM_PEAK, 4),
+            "min_frac": min(v["frac"] for v in table.values()), "widths_with_wrong_bytes": wrong,
+            "timing": f"best of {reps} launches per width, HIP events", "per_width": table}
 
 
 def measured_traffic(nblocks):
@@ -163,6 +198,7 @@ def main():
     ap.add_argument("--log2n", type=int, default=30, help="log2 of docIDs per GPU")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-h2h", action="store_true", help="skip the host-to-host leg")
+    ap.add_argument("--no-encode", action="store_true", help="skip the encoder leg")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -180,8 +216,9 @@ def main():
 
     corpora = {}
     verify = torch.zeros(2, dtype=torch.int64, device=dev)
+    seed0 = 1000 * (first % 100003)
     for b in WIDTHS:
-        payload, offsets, acc = build_corpus(nblocks, b, seed=1000 * (first % 100003) + b, dev=dev)
+        payload, offsets, acc = build_corpus(nblocks, b, seed=seed0 + b, dev=dev)
         corpora[b] = (payload, offsets)
         verify += acc
     out = torch.empty(nblocks * 128, dtype=torch.int32, device=dev)
@@ -261,6 +298,9 @@ def main():
                          "min_frac": min(v["frac"] for v in table.values()),
                          "per_width": table},
         }
+        if not a.no_encode:
+            del out
+            line["encode"] = encode_leg(corpora, nblocks, seed0, dev)
         if not a.no_cpu:
             line["cpu_baseline"] = cpu_baseline()
         if not a.no_h2h:
