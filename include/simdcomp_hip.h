@@ -139,6 +139,43 @@ int simdcomp_hip_packFOR_length(uint32_t initvalue, const uint32_t *d_in, size_t
 int simdcomp_hip_unpackFOR_length(uint32_t initvalue, const void *d_in, size_t length, uint32_t *d_out,
                                   uint32_t bit, void *stream);
 
+/* ---- the callers either side of the block codec ----------------------------- */
+
+/* Chained differential decode WITHOUT stored per-block offsets, the decode loop
+ * of example.c:101-110 (`offset = backbuffer[SIMDBlockSize - 1]` after every
+ * block): computes d_initvalues_out[k] = the offset simdunpackd1 must be given
+ * for block k when block 0 starts from `initvalue`.  A 32-bit block holds raw
+ * values and restarts the chain at its last one, a 0-bit block passes the
+ * offset on (src/simdintegratedbitpacking.c:21-35, :24903-24913).  Follow with
+ * simdcomp_hip_unpack_mixed(SIMDCOMP_HIP_D1, d_initvalues_out, ...).
+ * d_workspace: simdcomp_hip_chain_workspace(nblocks) bytes, 16-byte aligned. */
+size_t simdcomp_hip_chain_workspace(size_t nblocks);
+int simdcomp_hip_chain_offsets(uint32_t initvalue, const void *d_payload, const uint64_t *d_payload_offsets,
+                               const uint8_t *d_bits, size_t nblocks, uint32_t *d_initvalues_out, void *d_workspace,
+                               void *stream);
+
+/* The byte stream example.c:56-75 and :135-150 write: per block one width byte
+ * followed by its 16*b payload bytes (`*buffer++ = b; ... buffer += b *
+ * sizeof(__m128i)`).  Record k starts at byte d_payload_offsets[k] + k; the
+ * whole stream is nblocks + (total payload bytes) long; no alignment is
+ * required of d_stream.  build copies an aligned payload arena into such a
+ * stream, unbuild copies the payloads of a stream back into an aligned arena. */
+int simdcomp_hip_stream_build(const void *d_payload, const uint64_t *d_payload_offsets, const uint8_t *d_bits,
+                              size_t nblocks, void *d_stream, void *stream);
+int simdcomp_hip_stream_unbuild(const void *d_stream, const uint64_t *d_payload_offsets, const uint8_t *d_bits,
+                                size_t nblocks, void *d_payload, void *stream);
+/* Finds the records of such a stream from its bytes alone (what the decode
+ * loop of example.c:103-110 does one record at a time): writes the width and
+ * the arena offset of every record (at most max_blocks of them) and
+ * d_result[0] = number of records, d_result[1] = total payload bytes,
+ * d_result[2] = 0 if the stream parsed cleanly to its last byte, 1 if it holds
+ * a width byte above 32 or ends inside a record (then only d_result[2] is
+ * meaningful).  d_workspace: simdcomp_hip_stream_index_workspace(stream_bytes)
+ * bytes, 16-byte aligned. */
+size_t simdcomp_hip_stream_index_workspace(size_t stream_bytes);
+int simdcomp_hip_stream_index(const void *d_stream, size_t stream_bytes, size_t max_blocks, uint8_t *d_bits,
+                              uint64_t *d_payload_offsets, uint64_t *d_result, void *d_workspace, void *stream);
+
 /* ---- block-range partitioner and verification reduction -------------------- */
 
 /* Contiguous block range of shard `part` out of `nparts`: blocks are

@@ -275,6 +275,16 @@ class Oracle(BlockCodec):
         L.orc_compressedbytes.argtypes = [C.c_int64, u32]
         L.cpu_driver_time.restype = C.c_double
         L.cpu_driver_time.argtypes = [C.c_int, vp, vp, vp, vp, u32, C.c_size_t, C.c_int, C.c_int]
+        L.stream_compress_d1.restype = C.c_size_t
+        L.stream_compress_d1.argtypes = [vp, vp, vp, C.c_size_t, u32, vp]
+        L.stream_compress_plain.restype = C.c_size_t
+        L.stream_compress_plain.argtypes = [vp, vp, vp, C.c_size_t, vp]
+        L.stream_decode_d1.restype = None
+        L.stream_decode_d1.argtypes = [vp, vp, C.c_size_t, u32, vp]
+        L.stream_decode_plain.restype = None
+        L.stream_decode_plain.argtypes = [vp, vp, C.c_size_t, vp]
+        L.stream_walk.restype = C.c_size_t
+        L.stream_walk.argtypes = [vp, C.c_size_t, C.c_size_t, vp, vp, vp]
 
     MODES = {"plain": 0, "d1": 1, "for": 2}
 
@@ -319,6 +329,40 @@ class Oracle(BlockCodec):
 
     def compressedbytes64(self, n, bit):
         return int(self.lib.orc_compressedbytes(int(n), bit))
+
+    # -- the caller loops of example.c; `codec` is the BlockCodec whose block routines run inside them -------
+    def stream_compress(self, x, d1=True, initvalue=0, codec=None):
+        """example.c:56-75 (d1) / :135-150 (plain) -> uint8 stream."""
+        codec = codec or self
+        nblocks = x.size // 128
+        buf = np.zeros(nblocks * 513 + 16, dtype=np.uint8)
+        if d1:
+            n = self.lib.stream_compress_d1(C.cast(codec._maxbitsd1, vp), C.cast(codec._packwmd1, vp), _ptr(x), nblocks,
+                                            int(initvalue), _ptr(buf))
+        else:
+            n = self.lib.stream_compress_plain(C.cast(codec._maxbits, vp), C.cast(codec._packwm, vp), _ptr(x), nblocks,
+                                               _ptr(buf))
+        return buf[:n].copy()
+
+    def stream_decode(self, stream, nblocks, d1=True, initvalue=0, codec=None):
+        """example.c:101-110 (d1) / :170-175 (plain)."""
+        codec = codec or self
+        out = np.zeros(nblocks * 128, dtype=np.uint32)
+        stream = np.ascontiguousarray(stream)
+        if d1:
+            self.lib.stream_decode_d1(C.cast(codec._unpackd1, vp), _ptr(stream), nblocks, int(initvalue), _ptr(out))
+        else:
+            self.lib.stream_decode_plain(C.cast(codec._unpack, vp), _ptr(stream), nblocks, _ptr(out))
+        return out
+
+    def stream_walk(self, stream, max_blocks):
+        """-> (records found, bits[max_blocks], arena offsets[max_blocks], status)."""
+        stream = np.ascontiguousarray(stream)
+        bits = np.zeros(max_blocks, dtype=np.uint8)
+        off = np.zeros(max_blocks, dtype=np.uint64)
+        status = C.c_int(0)
+        n = self.lib.stream_walk(_ptr(stream), stream.size, max_blocks, _ptr(bits), _ptr(off), C.byref(status))
+        return int(n), bits, off, status.value
 
     def time_blocks(self, kind, fn_ptr, seeds, payload, ints, bit, nblocks, nthreads, reps):
         """Best-of-reps wall seconds for one pass; kind 0 unpack seeded, 1 unpack plain,

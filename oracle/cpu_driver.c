@@ -103,3 +103,85 @@ double cpu_driver_time(int kind, void *fn, const uint32_t *seeds, uint8_t *paylo
   free(jobs);
   return best;
 }
+
+/* ---- the caller loops of example.c, with the block routines passed in --------
+ * so that the very same loop runs over the compiled reference or over the
+ * scalar restatement. */
+typedef uint32_t (*maxbitsd1_fn)(uint32_t, const uint32_t *);
+typedef uint32_t (*maxbits_fn)(const uint32_t *);
+
+/* example.c:56-75: per block the width byte, then the payload; d1 offset = last
+ * value of the previous block.  Returns the number of bytes written. */
+size_t stream_compress_d1(void *maxbitsd1, void *packd1, const uint32_t *in, size_t nblocks, uint32_t initvalue,
+                          uint8_t *buffer) {
+  uint8_t *start = buffer;
+  uint32_t offset = initvalue;
+  size_t k;
+  for (k = 0; k < nblocks; ++k) {
+    uint32_t b = ((maxbitsd1_fn)maxbitsd1)(offset, in + k * 128);
+    *buffer++ = (uint8_t)b;
+    ((pack_seeded_fn)packd1)(offset, in + k * 128, buffer, b);
+    offset = in[k * 128 + 127];
+    buffer += b * 16;
+  }
+  return (size_t)(buffer - start);
+}
+
+/* example.c:135-150: the same stream without differential coding. */
+size_t stream_compress_plain(void *maxbits, void *pack, const uint32_t *in, size_t nblocks, uint8_t *buffer) {
+  uint8_t *start = buffer;
+  size_t k;
+  for (k = 0; k < nblocks; ++k) {
+    uint32_t b = ((maxbits_fn)maxbits)(in + k * 128);
+    *buffer++ = (uint8_t)b;
+    ((pack_plain_fn)pack)(in + k * 128, buffer, b);
+    buffer += b * 16;
+  }
+  return (size_t)(buffer - start);
+}
+
+/* example.c:101-110: decode with no stored offsets, offset = last decoded value. */
+void stream_decode_d1(void *unpackd1, const uint8_t *buffer, size_t nblocks, uint32_t initvalue, uint32_t *out) {
+  uint32_t offset = initvalue;
+  size_t k;
+  for (k = 0; k < nblocks; ++k) {
+    uint8_t b = *buffer++;
+    ((unpack_seeded_fn)unpackd1)(offset, buffer, out + k * 128, b);
+    buffer += (size_t)b * 16;
+    offset = out[k * 128 + 127];
+  }
+}
+
+/* example.c:170-175 (the plain decode loop). */
+void stream_decode_plain(void *unpack, const uint8_t *buffer, size_t nblocks, uint32_t *out) {
+  size_t k;
+  for (k = 0; k < nblocks; ++k) {
+    uint8_t b = *buffer++;
+    ((unpack_plain_fn)unpack)(buffer, out + k * 128, b);
+    buffer += (size_t)b * 16;
+  }
+}
+
+/* The record walk those decode loops perform, on its own: widths and arena
+ * offsets (stream position minus record number) of the records in
+ * buffer[0..nbytes).  Returns the number of records; *status = 1 when a width
+ * byte exceeds 32 or the last record is cut short. */
+size_t stream_walk(const uint8_t *buffer, size_t nbytes, size_t max_blocks, uint8_t *bits, uint64_t *off, int *status) {
+  size_t p = 0, k = 0;
+  *status = 0;
+  while (p < nbytes) {
+    uint8_t b = buffer[p];
+    if (b > 32) {
+      *status = 1;
+      return k;
+    }
+    if (k < max_blocks) {
+      bits[k] = b;
+      off[k] = (uint64_t)(p - k);
+    }
+    p += 1 + 16 * (size_t)b;
+    ++k;
+  }
+  if (p != nbytes) *status = 1;
+  return k;
+}

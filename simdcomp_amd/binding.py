@@ -31,6 +31,12 @@ DEVICE_API = {
     "simdcomp_hip_reduce_length": (C.c_int, [vp, sz, u32, vp, vp]),
     "simdcomp_hip_payload_offsets_workspace": (sz, [sz]),
     "simdcomp_hip_payload_offsets": (C.c_int, [vp, sz, vp, vp, vp, vp]),
+    "simdcomp_hip_chain_workspace": (sz, [sz]),
+    "simdcomp_hip_chain_offsets": (C.c_int, [u32, vp, vp, vp, sz, vp, vp, vp]),
+    "simdcomp_hip_stream_build": (C.c_int, [vp, vp, vp, sz, vp, vp]),
+    "simdcomp_hip_stream_unbuild": (C.c_int, [vp, vp, vp, sz, vp, vp]),
+    "simdcomp_hip_stream_index_workspace": (sz, [sz]),
+    "simdcomp_hip_stream_index": (C.c_int, [vp, sz, sz, vp, vp, vp, vp, vp]),
     "simdcomp_hip_compressedbytes": (sz, [sz, u32]),
     "simdcomp_hip_pack_length": (C.c_int, [vp, sz, vp, u32, vp]),
     "simdcomp_hip_unpack_length": (C.c_int, [vp, sz, vp, u32, vp]),

@@ -145,6 +145,50 @@ def unpack_mixed(mode, payload, bits, offsets, nblocks, initvalues=None, out=Non
     return out
 
 
+def chain_offsets(payload, bits, offsets, initvalue=0, out=None):
+    """Offsets simdunpackd1 needs per block when none were stored (example.c:101-110)."""
+    nblocks = bits.numel()
+    if out is None:
+        out = torch.empty(nblocks, dtype=torch.int32, device=bits.device)
+    ws = torch.empty(max(16, B.lib().simdcomp_hip_chain_workspace(nblocks)), dtype=torch.uint8, device=bits.device)
+    B.check(B.lib().simdcomp_hip_chain_offsets(_s32(initvalue), B.ptr(payload), B.ptr(offsets), B.ptr(bits), nblocks,
+                                               B.ptr(out), B.ptr(ws), _stream()), "chain_offsets")
+    return out
+
+
+def stream_build(payload, bits, offsets, total_bytes, out=None):
+    """Aligned arena -> the [b][payload] byte stream of example.c:56-75."""
+    nblocks = bits.numel()
+    if out is None:
+        out = torch.empty(nblocks + total_bytes, dtype=torch.uint8, device=bits.device)
+    B.check(B.lib().simdcomp_hip_stream_build(B.ptr(payload), B.ptr(offsets), B.ptr(bits), nblocks, B.ptr(out),
+                                              _stream()), "stream_build")
+    return out
+
+
+def stream_unbuild(stream, bits, offsets, total_bytes, out=None):
+    """Payloads of a [b][payload] stream -> 16-byte aligned arena."""
+    nblocks = bits.numel()
+    if out is None:
+        out = torch.empty(total_bytes + 16, dtype=torch.uint8, device=bits.device)
+    B.check(B.lib().simdcomp_hip_stream_unbuild(B.ptr(stream), B.ptr(offsets), B.ptr(bits), nblocks, B.ptr(out),
+                                                _stream()), "stream_unbuild")
+    return out
+
+
+def stream_index(stream, max_blocks, nbytes=None):
+    """-> (bits uint8[max_blocks], offsets int64[max_blocks], result int64[3] = records, payload bytes, status)."""
+    nbytes = stream.numel() if nbytes is None else nbytes
+    dev = stream.device
+    bits = torch.empty(max_blocks, dtype=torch.uint8, device=dev)
+    off = torch.empty(max_blocks, dtype=torch.int64, device=dev)
+    res = torch.empty(3, dtype=torch.int64, device=dev)
+    ws = torch.empty(max(16, B.lib().simdcomp_hip_stream_index_workspace(nbytes)), dtype=torch.uint8, device=dev)
+    B.check(B.lib().simdcomp_hip_stream_index(B.ptr(stream), nbytes, max_blocks, B.ptr(bits), B.ptr(off), B.ptr(res),
+                                              B.ptr(ws), _stream()), "stream_index")
+    return bits, off, res
+
+
 def pack_length(x, bit, out=None):
     x = _i32(x)
     n = x.numel()

@@ -7,6 +7,7 @@
 
 #include "../../include/simdcomp_hip.h"
 #include "codec_kernels.h"
+#include "stream_kernels.h"
 
 namespace {
 
@@ -304,6 +305,53 @@ int simdcomp_hip_partition_by_bytes(const uint64_t *h_payload_offsets, size_t nb
   *first = a;
   *count = b - a;
   return SIMDCOMP_HIP_OK;
+}
+
+size_t simdcomp_hip_chain_workspace(size_t nblocks) { return sc::chain_workspace_bytes(nblocks); }
+
+int simdcomp_hip_chain_offsets(uint32_t initvalue, const void *d_payload, const uint64_t *d_payload_offsets,
+                               const uint8_t *d_bits, size_t nblocks, uint32_t *d_initvalues_out, void *d_workspace,
+                               void *stream) {
+  if (nblocks == 0) return SIMDCOMP_HIP_OK;
+  if (!d_payload || !d_payload_offsets || !d_bits || !d_initvalues_out || !d_workspace)
+    return fail(SIMDCOMP_HIP_ENULL, "NULL pointer");
+  if (!aligned16(d_payload) || !aligned16(d_workspace)) return fail(SIMDCOMP_HIP_EALIGN, "pointer not 16-byte aligned");
+  return hip_result(sc::launch_chain_offsets(initvalue, d_payload, d_payload_offsets, d_bits, nblocks, d_initvalues_out,
+                                             d_workspace, as_stream(stream)),
+                    "chain offsets launch");
+}
+
+int simdcomp_hip_stream_build(const void *d_payload, const uint64_t *d_payload_offsets, const uint8_t *d_bits,
+                              size_t nblocks, void *d_stream, void *stream) {
+  if (nblocks == 0) return SIMDCOMP_HIP_OK;
+  if (!d_payload || !d_payload_offsets || !d_bits || !d_stream) return fail(SIMDCOMP_HIP_ENULL, "NULL pointer");
+  if (!aligned16(d_payload)) return fail(SIMDCOMP_HIP_EALIGN, "payload arena not 16-byte aligned");
+  return hip_result(sc::launch_stream_build(d_payload, d_payload_offsets, d_bits, nblocks,
+                                            static_cast<uint8_t *>(d_stream), as_stream(stream)),
+                    "stream build launch");
+}
+
+int simdcomp_hip_stream_unbuild(const void *d_stream, const uint64_t *d_payload_offsets, const uint8_t *d_bits,
+                                size_t nblocks, void *d_payload, void *stream) {
+  if (nblocks == 0) return SIMDCOMP_HIP_OK;
+  if (!d_payload || !d_payload_offsets || !d_bits || !d_stream) return fail(SIMDCOMP_HIP_ENULL, "NULL pointer");
+  if (!aligned16(d_payload)) return fail(SIMDCOMP_HIP_EALIGN, "payload arena not 16-byte aligned");
+  return hip_result(sc::launch_stream_unbuild(static_cast<const uint8_t *>(d_stream), d_payload_offsets, d_bits, nblocks,
+                                              d_payload, as_stream(stream)),
+                    "stream unbuild launch");
+}
+
+size_t simdcomp_hip_stream_index_workspace(size_t stream_bytes) { return sc::stream_index_workspace_bytes(stream_bytes); }
+
+int simdcomp_hip_stream_index(const void *d_stream, size_t stream_bytes, size_t max_blocks, uint8_t *d_bits,
+                              uint64_t *d_payload_offsets, uint64_t *d_result, void *d_workspace, void *stream) {
+  if (!d_result) return fail(SIMDCOMP_HIP_ENULL, "result pointer is NULL");
+  if (stream_bytes && (!d_stream || !d_workspace)) return fail(SIMDCOMP_HIP_ENULL, "NULL pointer");
+  if (stream_bytes && max_blocks && (!d_bits || !d_payload_offsets)) return fail(SIMDCOMP_HIP_ENULL, "NULL output array");
+  if (!aligned16(d_workspace)) return fail(SIMDCOMP_HIP_EALIGN, "workspace not 16-byte aligned");
+  return hip_result(sc::launch_stream_index(static_cast<const uint8_t *>(d_stream), stream_bytes, max_blocks, d_bits,
+                                            d_payload_offsets, d_result, d_workspace, as_stream(stream)),
+                    "stream index launch");
 }
 
 int simdcomp_hip_checksum(const uint32_t *d_data, const uint32_t *d_other, size_t nwords, uint64_t index0,

@@ -43,3 +43,21 @@ def corpus_mixed(nblk):
     gaps = (gaps & m[:, None]).reshape(-1).astype(np.uint64)
     v = (np.cumsum(gaps) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
     return v, synth.block_offsets(v, 0)
+
+
+def stream_corpus(seed, nblk):
+    """Integers for the example.c byte-stream tests: mostly sorted with per-block
+    gap widths 1..20, plus runs of equal values (0-bit blocks, which pass the
+    differential offset through) and blocks of arbitrary 32-bit values (32-bit
+    blocks, which restart it)."""
+    widths = synth.skewed_widths(seed, nblk, 1, 20)
+    kind = synth.rand_u32(seed + 1, nblk) % np.uint32(16)
+    gaps = synth.rand_u32(seed + 2, nblk * 128).reshape(nblk, 128)
+    m = ((np.uint64(1) << widths.astype(np.uint64)) - np.uint64(1)).astype(np.uint32)
+    gaps = gaps & m[:, None]
+    gaps[kind == 0] = 0
+    v = (np.cumsum(gaps.reshape(-1).astype(np.uint64)) & np.uint64(0xFFFFFFFF)).astype(np.uint32).reshape(nblk, 128)
+    wild = synth.rand_u32(seed + 3, nblk * 128).reshape(nblk, 128) | np.uint32(0x80000000)
+    wild[:, 1::2] &= np.uint32(0x7FFFFFFF)  # alternate high/low so that successive differences need all 32 bits
+    v[kind == 1] = wild[kind == 1]
+    return np.ascontiguousarray(v.reshape(-1))

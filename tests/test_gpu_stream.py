@@ -1,0 +1,178 @@
+"""Device-side handling of the example.c byte stream ([width byte][payload] per
+block, example.c:56-75) and of chained differential decoding without stored
+offsets (example.c:101-110), through the C ABI, against the CPU loops run over
+the oracle and against the streams the reference itself wrote (tests/golden)."""
+import numpy as np
+import pytest
+
+import golden_util as G
+
+pytestmark = pytest.mark.gpu
+
+D1, PLAIN = 1, 0
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from simdcomp_amd import codec
+
+    return codec
+
+
+def to_dev(a):
+    import torch
+
+    a = np.ascontiguousarray(a)
+    if a.dtype == np.uint32:
+        return torch.from_numpy(a.view(np.int32)).cuda()
+    if a.dtype == np.uint64:
+        return torch.from_numpy(a.view(np.int64)).cuda()
+    return torch.from_numpy(a).cuda()
+
+
+def u32(t):
+    return t.cpu().numpy().view(np.uint32)
+
+
+def compress_on_device(dev, x, d1=True):
+    """example.c:56-75 on the device: widths, offsets scan, pack, stream build."""
+    import torch
+
+    d_x = to_dev(x)
+    seeds = torch.empty(x.size // 128, dtype=torch.int32, device="cuda")
+    bits = dev.maxbitsd1(d_x, initvalue=0, initvalues_out=seeds) if d1 else dev.maxbits(d_x)
+    off, total = dev.payload_offsets(bits)
+    nbytes = int(total.item())
+    arena = torch.zeros(nbytes + 16, dtype=torch.uint8, device="cuda")
+    dev.pack_mixed(D1 if d1 else PLAIN, d_x, bits, off, arena, initvalues=seeds if d1 else None)
+    stream = dev.stream_build(arena, bits, off, nbytes)
+    return stream, arena, bits, off, seeds, nbytes
+
+
+@pytest.mark.parametrize("d1", [True, False])
+def test_golden_stream_round_trip(dev, d1):
+    """The device writes byte for byte the stream the reference wrote, and reads it back."""
+    g = G.load("stream.npz")
+    nblk = int(g["nblocks"])
+    want = g["d1" if d1 else "plain"]
+    x = G.stream_corpus(900, nblk)
+    stream, arena, bits, off, seeds, nbytes = compress_on_device(dev, x, d1)
+    assert np.array_equal(stream.cpu().numpy(), want)
+    # decode from the bytes alone: index -> re-aligned arena -> (chained offsets) -> unpack
+    ibits, ioff, res = dev.stream_index(to_dev(want), nblk)
+    assert res.tolist() == [nblk, want.size - nblk, 0]
+    assert np.array_equal(ibits.cpu().numpy(), bits.cpu().numpy())
+    assert np.array_equal(ioff.cpu().numpy(), off.cpu().numpy())
+    arena2 = dev.stream_unbuild(to_dev(want), ibits, ioff, nbytes)
+    assert np.array_equal(arena2.cpu().numpy()[:nbytes], arena.cpu().numpy()[:nbytes])
+    if d1:
+        chained = dev.chain_offsets(arena2, ibits, ioff, initvalue=0)
+        assert np.array_equal(u32(chained), u32(seeds))
+        out = dev.unpack_mixed(D1, arena2, ibits, ioff, nblk, initvalues=chained)
+    else:
+        out = dev.unpack_mixed(PLAIN, arena2, ibits, ioff, nblk)
+    assert np.array_equal(u32(out), x)
+
+
+@pytest.mark.parametrize("nblk", [1, 2, 9, 130, 4097, 70001])
+def test_stream_sizes_and_alignments(dev, orc, nblk):
+    """Record counts around the scan tiles and index chunks; the stream buffer at every byte alignment."""
+    import torch
+
+    x = G.stream_corpus(40 + nblk, nblk)
+    want = orc.stream_compress(x, d1=True, initvalue=0)
+    stream, arena, bits, off, seeds, nbytes = compress_on_device(dev, x)
+    assert np.array_equal(stream.cpu().numpy(), want)
+    n, wbits, woff, status = orc.stream_walk(want, nblk)
+    assert (n, status) == (nblk, 0)
+    for shift in (1, 2, 3, 5):
+        buf = torch.full((want.size + 16,), 0xEE, dtype=torch.uint8, device="cuda")
+        view = buf[shift:shift + want.size]
+        dev.stream_build(arena, bits, off, nbytes, out=view)
+        got = buf.cpu().numpy()
+        assert np.array_equal(got[shift:shift + want.size], want)
+        assert (got[:shift] == 0xEE).all() and (got[shift + want.size:] == 0xEE).all(), "wrote outside the stream"
+        ibits, ioff, res = dev.stream_index(view, nblk + 5)
+        assert res.tolist() == [nblk, want.size - nblk, 0]
+        assert np.array_equal(ibits.cpu().numpy()[:nblk], wbits)
+        assert np.array_equal(ioff.cpu().numpy()[:nblk].view(np.uint64), woff)
+        arena2 = torch.full((nbytes + 32,), 0xCC, dtype=torch.uint8, device="cuda")
+        dev.stream_unbuild(view, ibits[:nblk], ioff[:nblk], nbytes, out=arena2)
+        got = arena2.cpu().numpy()
+        assert np.array_equal(got[:nbytes], arena.cpu().numpy()[:nbytes])
+        assert (got[nbytes:] == 0xCC).all(), "wrote outside the arena"
+    for init in (0, 0xDEADBEEF):
+        # offsets chained from another start value: decode equals the CPU loop of example.c:101-110
+        chained = dev.chain_offsets(arena, bits, off, initvalue=init)
+        out = dev.unpack_mixed(D1, arena, bits, off, nblk, initvalues=chained)
+        assert np.array_equal(u32(out), orc.stream_decode(want, nblk, d1=True, initvalue=init))
+
+
+def test_index_rejects_bad_streams(dev, orc):
+    x = G.stream_corpus(77, 3000)
+    s = orc.stream_compress(x, d1=True)
+    d = to_dev(s)
+    assert dev.stream_index(d, 3000)[2].tolist()[2] == 0
+    assert dev.stream_index(d[:-1], 3000)[2].tolist()[2] == 1  # ends inside a record
+    n, bits, off, _ = orc.stream_walk(s, 3000)
+    for k in (0, 1500, 2999):
+        bad = s.copy()
+        bad[int(off[k]) + k] = 33 + k % 200
+        assert dev.stream_index(to_dev(bad), 3000)[2].tolist()[2] == 1
+    # payload bytes above 32 are not width bytes and do not matter
+    assert (s > 32).any()
+    # empty stream
+    import torch
+
+    assert dev.stream_index(torch.empty(0, dtype=torch.uint8, device="cuda"), 4)[2].tolist() == [0, 0, 0]
+
+
+def test_index_dense_and_sparse_records(dev, orc):
+    """All-zero widths (one record per byte: tens of thousands of records per index chunk) and all-32 widths."""
+    import torch
+
+    n0 = 200001
+    z = torch.zeros(n0, dtype=torch.uint8, device="cuda")
+    bits, off, res = dev.stream_index(z, n0)
+    assert res.tolist() == [n0, 0, 0]
+    assert int(bits.max().item()) == 0 and int(off.max().item()) == 0
+    nblk = 3001
+    x = (np.arange(nblk * 128, dtype=np.uint32) * np.uint32(2654435761)) ^ np.uint32(0x5A5A5A5A)
+    s = orc.stream_compress(x, d1=True)
+    assert s.size == nblk * 513
+    bits, off, res = dev.stream_index(to_dev(s), nblk)
+    assert res.tolist() == [nblk, nblk * 512, 0]
+    assert (bits == 32).all() and np.array_equal(off.cpu().numpy(), np.arange(nblk, dtype=np.int64) * 512)
+
+
+def test_large_stream_2p27(dev):
+    """2^27 integers: device compress -> stream -> index -> unbuild -> chain -> decode equals the input."""
+    import torch
+
+    nblk = (1 << 27) // 128
+    w = torch.minimum(torch.randint(0, 21, (nblk,), device="cuda"), torch.randint(0, 21, (nblk,), device="cuda"))
+    gaps = torch.randint(0, 1 << 30, (nblk * 128,), dtype=torch.int32, device="cuda")
+    gaps &= ((1 << w) - 1).to(torch.int32).repeat_interleave(128)
+    ids = torch.cumsum(gaps, 0, dtype=torch.int32)
+    wild = torch.randint(0, nblk, (nblk // 50,), device="cuda")
+    ids.view(-1, 128)[wild] = torch.randint(-2 ** 31, 2 ** 31 - 1, (wild.numel(), 128), dtype=torch.int32, device="cuda")
+    seeds = torch.empty(nblk, dtype=torch.int32, device="cuda")
+    bits = dev.maxbitsd1(ids, initvalue=0, initvalues_out=seeds)
+    assert int((bits == 32).sum().item()) > 0 and int((bits == 0).sum().item()) > 0
+    off, total = dev.payload_offsets(bits)
+    nbytes = int(total.item())
+    arena = torch.empty(nbytes + 16, dtype=torch.uint8, device="cuda")
+    dev.pack_mixed(D1, ids, bits, off, arena, initvalues=seeds)
+    stream = dev.stream_build(arena, bits, off, nbytes)
+    ibits, ioff, res = dev.stream_index(stream, nblk)
+    assert res.tolist() == [nblk, nbytes, 0]
+    assert torch.equal(ibits, bits) and torch.equal(ioff, off)
+    arena2 = dev.stream_unbuild(stream, ibits, ioff, nbytes)
+    assert torch.equal(arena2[:nbytes], arena[:nbytes])
+    chained = dev.chain_offsets(arena2, ibits, ioff, initvalue=0)
+    assert torch.equal(chained, seeds)
+    out = dev.unpack_mixed(D1, arena2, ibits, ioff, nblk, initvalues=chained)
+    assert int(dev.checksum(out, other=ids)[1].item()) == 0

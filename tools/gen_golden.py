@@ -19,6 +19,9 @@ Files written
   corpus.npz    FNV-1a-64 digests of packed payload and decoded output for
                 seeded multi-thousand-block corpora (plain / d1 / FOR, uniform
                 widths and a mixed-width d1 stream)
+  stream.npz    the [width byte][payload] byte streams of example.c:56-75 (d1)
+                and :135-150 (plain) over 600 blocks that include 0-bit and
+                32-bit blocks, written by the reference's block routines
 """
 import os
 import sys
@@ -157,6 +160,20 @@ def gen_corpus(ref):
                         nblocks=np.uint64(nblk))
 
 
+def gen_stream(ref):
+    """The example.c byte streams produced by the reference's own block routines."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import golden_util
+
+    nblk = 600
+    x = golden_util.stream_corpus(900, nblk)
+    d1 = ORC.stream_compress(x, d1=True, initvalue=0, codec=ref)
+    plain = ORC.stream_compress(x, d1=False, codec=ref)
+    assert np.array_equal(ORC.stream_decode(d1, nblk, d1=True, codec=ref), x)
+    assert np.array_equal(ORC.stream_decode(plain, nblk, d1=False, codec=ref), x)
+    np.savez_compressed(os.path.join(OUT, "stream.npz"), nblocks=np.uint64(nblk), d1=d1, plain=plain)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     ORC = oracle.Oracle()  # used only for its FNV helper
@@ -164,5 +181,6 @@ if __name__ == "__main__":
     gen_blocks(REF)
     gen_lengths(REF)
     gen_corpus(REF)
+    gen_stream(REF)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
