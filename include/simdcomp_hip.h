@@ -147,19 +147,36 @@ int simdcomp_hip_unpackFOR_length(uint32_t initvalue, const void *d_in, size_t l
  * for block k when block 0 starts from `initvalue`.  A 32-bit block holds raw
  * values and restarts the chain at its last one, a 0-bit block passes the
  * offset on (src/simdintegratedbitpacking.c:21-35, :24903-24913).  Follow with
- * simdcomp_hip_unpack_mixed(SIMDCOMP_HIP_D1, d_initvalues_out, ...).
- * d_workspace: simdcomp_hip_chain_workspace(nblocks) bytes, 16-byte aligned. */
+ * simdcomp_hip_unpack_mixed / _unpack_stream (SIMDCOMP_HIP_D1, d_initvalues_out).
+ * stream_layout = 0: d_payload is the aligned arena; 1: it is the byte stream
+ * described below.  d_workspace: simdcomp_hip_chain_workspace(nblocks) bytes,
+ * 16-byte aligned. */
 size_t simdcomp_hip_chain_workspace(size_t nblocks);
 int simdcomp_hip_chain_offsets(uint32_t initvalue, const void *d_payload, const uint64_t *d_payload_offsets,
-                               const uint8_t *d_bits, size_t nblocks, uint32_t *d_initvalues_out, void *d_workspace,
-                               void *stream);
+                               const uint8_t *d_bits, size_t nblocks, int stream_layout, uint32_t *d_initvalues_out,
+                               void *d_workspace, void *stream);
 
 /* The byte stream example.c:56-75 and :135-150 write: per block one width byte
  * followed by its 16*b payload bytes (`*buffer++ = b; ... buffer += b *
- * sizeof(__m128i)`).  Record k starts at byte d_payload_offsets[k] + k; the
- * whole stream is nblocks + (total payload bytes) long; no alignment is
- * required of d_stream.  build copies an aligned payload arena into such a
- * stream, unbuild copies the payloads of a stream back into an aligned arena. */
+ * sizeof(__m128i)`).  Record k starts at byte d_payload_offsets[k] + k, where
+ * d_payload_offsets is the same exclusive scan of 16*b the aligned arena uses;
+ * the whole stream is nblocks + (total payload bytes) long; no alignment is
+ * required of d_stream (the reference reads and writes it with loadu/storeu,
+ * example.c:68-72; here it is byte-addressed 16-byte global accesses).
+ *
+ * pack_stream / unpack_stream are pack_mixed / unpack_mixed working on such a
+ * stream in place (pack_stream also writes the width bytes): with
+ * simdcomp_hip_maxbitsd1 and simdcomp_hip_payload_offsets in front,
+ * pack_stream is example.c:56-75 (SIMDCOMP_HIP_D1, masked = 0, chained) or
+ * :135-150 (SIMDCOMP_HIP_PLAIN after simdcomp_hip_maxbits). */
+int simdcomp_hip_pack_stream(int mode, int masked, uint32_t initvalue, const uint32_t *d_initvalues,
+                             const uint32_t *d_in, void *d_stream, const uint64_t *d_payload_offsets,
+                             const uint8_t *d_bits, size_t nblocks, uint32_t *d_initvalues_out, void *stream);
+int simdcomp_hip_unpack_stream(int mode, const uint32_t *d_initvalues, const void *d_stream,
+                               const uint64_t *d_payload_offsets, const uint8_t *d_bits, uint32_t *d_out,
+                               size_t nblocks, void *stream);
+/* build copies an aligned payload arena into such a stream, unbuild copies the
+ * payloads of a stream back into an aligned arena. */
 int simdcomp_hip_stream_build(const void *d_payload, const uint64_t *d_payload_offsets, const uint8_t *d_bits,
                               size_t nblocks, void *d_stream, void *stream);
 int simdcomp_hip_stream_unbuild(const void *d_stream, const uint64_t *d_payload_offsets, const uint8_t *d_bits,

@@ -32,7 +32,9 @@ DEVICE_API = {
     "simdcomp_hip_payload_offsets_workspace": (sz, [sz]),
     "simdcomp_hip_payload_offsets": (C.c_int, [vp, sz, vp, vp, vp, vp]),
     "simdcomp_hip_chain_workspace": (sz, [sz]),
-    "simdcomp_hip_chain_offsets": (C.c_int, [u32, vp, vp, vp, sz, vp, vp, vp]),
+    "simdcomp_hip_chain_offsets": (C.c_int, [u32, vp, vp, vp, sz, C.c_int, vp, vp, vp]),
+    "simdcomp_hip_pack_stream": (C.c_int, [C.c_int, C.c_int, u32, vp, vp, vp, vp, vp, sz, vp, vp]),
+    "simdcomp_hip_unpack_stream": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, sz, vp]),
     "simdcomp_hip_stream_build": (C.c_int, [vp, vp, vp, sz, vp, vp]),
     "simdcomp_hip_stream_unbuild": (C.c_int, [vp, vp, vp, sz, vp, vp]),
     "simdcomp_hip_stream_index_workspace": (sz, [sz]),

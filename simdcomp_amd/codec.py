@@ -145,14 +145,33 @@ def unpack_mixed(mode, payload, bits, offsets, nblocks, initvalues=None, out=Non
     return out
 
 
-def chain_offsets(payload, bits, offsets, initvalue=0, out=None):
+def pack_stream(mode, x, bits, offsets, stream, initvalues=None, initvalue=0, masked=False, initvalues_out=None):
+    """pack_mixed writing the [b][payload] byte stream of example.c:56-75 in place."""
+    x = _i32(x)
+    nblocks = x.numel() // 128
+    B.check(B.lib().simdcomp_hip_pack_stream(mode, int(masked), _s32(initvalue), B.ptr(initvalues), B.ptr(x),
+                                             B.ptr(stream), B.ptr(offsets), B.ptr(bits), nblocks,
+                                             B.ptr(initvalues_out), _stream()), "pack_stream")
+    return stream
+
+
+def unpack_stream(mode, stream, bits, offsets, nblocks, initvalues=None, out=None):
+    """unpack_mixed reading the [b][payload] byte stream in place."""
+    if out is None:
+        out = torch.empty(nblocks * 128, dtype=torch.int32, device=stream.device)
+    B.check(B.lib().simdcomp_hip_unpack_stream(mode, B.ptr(initvalues), B.ptr(stream), B.ptr(offsets), B.ptr(bits),
+                                               B.ptr(out), nblocks, _stream()), "unpack_stream")
+    return out
+
+
+def chain_offsets(payload, bits, offsets, initvalue=0, out=None, stream_layout=False):
     """Offsets simdunpackd1 needs per block when none were stored (example.c:101-110)."""
     nblocks = bits.numel()
     if out is None:
         out = torch.empty(nblocks, dtype=torch.int32, device=bits.device)
     ws = torch.empty(max(16, B.lib().simdcomp_hip_chain_workspace(nblocks)), dtype=torch.uint8, device=bits.device)
     B.check(B.lib().simdcomp_hip_chain_offsets(_s32(initvalue), B.ptr(payload), B.ptr(offsets), B.ptr(bits), nblocks,
-                                               B.ptr(out), B.ptr(ws), _stream()), "chain_offsets")
+                                               int(stream_layout), B.ptr(out), B.ptr(ws), _stream()), "chain_offsets")
     return out
 
 

@@ -19,6 +19,10 @@ struct UnpackArgs {
   size_t length;           // TAIL kernels: number of valid integers
   uint32_t bit;
   uint32_t seed0;
+  // Per-block widths only: the payload of block k lies at payload + off[k] + (block_base + k) + 1, any alignment --
+  // the byte stream of example.c:56-75 (a width byte in front of every payload) decoded in place.
+  uint32_t stream_layout;
+  size_t block_base;       // stream layout: record number of this call's block 0
 };
 
 struct PackArgs {
@@ -35,6 +39,9 @@ struct PackArgs {
   int carry_blocks;        // GENERIC: hand the end-of-block spill to the next block (whole-array generic loop)
   size_t chain_base;       // d1 chain mode: index of this call's block 0 in the whole stream (0 = stream start)
   int carry_first;         // GENERIC: block 0 also receives a spill, from the row stored just before `in`
+  // Per-block widths only: write the byte stream of example.c:56-75 directly -- block k's width byte at
+  // payload + off[k] + (chain_base + k), its payload right behind it, any alignment.
+  uint32_t stream_layout;
 };
 
 struct ReduceArgs {

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void k_unpack_flex(UnpackArgs a) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int h = lane >> 5, k = lane & 31;
   u32x4 *slot = lds[wv][h];
-  const u32x4 *payload = reinterpret_cast<const u32x4 *>(a.payload);
+  const uint8_t *payload_bytes = static_cast<const uint8_t *>(a.payload);
   const size_t per_iter = (size_t)BLOCKS_PER_STEP * U;
   const size_t ntiles = (a.nblocks + per_iter - 1) / per_iter;
 
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void k_unpack_flex(UnpackArgs a) {
     size_t blk[U];
     bool valid[U];
     uint32_t b[U], seed[U];
-    size_t vbase[U];
+    const uint8_t *pbase[U];
     u32x4 ld[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -77,7 +77,12 @@ __global__ __launch_bounds__(256) void k_unpack_flex(UnpackArgs a) {
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      vbase[u] = a.off ? (valid[u] ? (size_t)(a.off[blk[u]] >> 4) : 0) : blk[u] * (size_t)b[u];
+      pbase[u] = payload_bytes;
+      if (a.off) {
+        if (valid[u]) pbase[u] += a.off[blk[u]] + (a.stream_layout ? a.block_base + blk[u] + 1 : 0);
+      } else {
+        pbase[u] += blk[u] * 16 * (size_t)b[u];
+      }
       if constexpr (MODE != MODE_PLAIN) {
         seed[u] = a.seeds ? (valid[u] ? a.seeds[blk[u]] : 0u) : a.seed0;
       }
@@ -91,7 +96,7 @@ __global__ __launch_bounds__(256) void k_unpack_flex(UnpackArgs a) {
         const size_t nval = start < a.length ? (a.length - start < 128 ? a.length - start : 128) : 0;
         nvec = (uint32_t)((((nval + 3) / 4) * b[u] + 31) / 32);
       }
-      if (valid[u] && (uint32_t)k < nvec) ld[u] = payload[vbase[u] + k];
+      if (valid[u] && (uint32_t)k < nvec) ld[u] = *reinterpret_cast<const u32x4_u *>(pbase[u] + 16 * k);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -169,7 +174,7 @@ template <int B, int MODE, bool MASKED, int U, bool GENERIC>
 __global__ __launch_bounds__(256) void k_pack_flex(PackArgs a) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int h = lane >> 5, k = lane & 31;
-  u32x4 *payload = reinterpret_cast<u32x4 *>(a.payload);
+  uint8_t *payload_bytes = static_cast<uint8_t *>(a.payload);
   const size_t per_iter = (size_t)BLOCKS_PER_STEP * U;
   const size_t ntiles = (a.nblocks + per_iter - 1) / per_iter;
 
@@ -178,7 +183,7 @@ __global__ __launch_bounds__(256) void k_pack_flex(PackArgs a) {
     size_t blk[U];
     bool valid[U];
     uint32_t b[U], seed[U];
-    size_t vbase[U];
+    uint8_t *pbase[U];
     u32x4 x[U], carry[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -192,7 +197,12 @@ __global__ __launch_bounds__(256) void k_pack_flex(PackArgs a) {
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      vbase[u] = a.off ? (valid[u] ? (size_t)(a.off[blk[u]] >> 4) : 0) : blk[u] * (size_t)b[u];
+      pbase[u] = payload_bytes;
+      if (a.off) {
+        if (valid[u]) pbase[u] += a.off[blk[u]] + (a.stream_layout ? a.chain_base + blk[u] + 1 : 0);
+      } else {
+        pbase[u] += blk[u] * 16 * (size_t)b[u];
+      }
       seed[u] = a.seed0;
       if constexpr (MODE == MODE_D1) {
         // explicit per-block offsets, or the chained stream of example.c:63-71:
@@ -298,10 +308,11 @@ __global__ __launch_bounds__(256) void k_pack_flex(PackArgs a) {
       }
       if (valid[u]) {
         if (raw) {
-          if (!GENERIC) payload[vbase[u] + k] = x[u];
+          if (!GENERIC) *reinterpret_cast<u32x4_u *>(pbase[u] + 16 * k) = x[u];
         } else if (last && w < nvec) {
-          payload[vbase[u] + w] = acc;
+          *reinterpret_cast<u32x4_u *>(pbase[u] + 16 * w) = acc;
         }
+        if (!GENERIC && a.off && a.stream_layout && k == 0) pbase[u][-1] = (uint8_t)bu;
         if (MODE == MODE_D1 && a.seeds_out && k == 0) a.seeds_out[blk[u]] = seed[u];
       }
     }
@@ -395,14 +406,14 @@ __global__ __launch_bounds__(BS) void k_unpack_fast(UnpackArgs a, uint32_t nwg =
   {
     const size_t first = tile * per_iter + (size_t)wv * 2 * U + h;
     uint32_t b[U], seed[U];
-    const u32x4 *src[U];
+    const u32x4_u *src[U];  // uniform widths: always 16-byte aligned; per-block widths: any alignment in stream layout
     u32x4 ld[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const size_t blk = first + 2 * (size_t)u;
       if constexpr (B >= 0) {
         b[u] = B;
-        src[u] = payload + blk * (size_t)B + (k < B ? k : (B ? B - 1 : 0));
+        src[u] = reinterpret_cast<const u32x4_u *>(payload + blk * (size_t)B + (k < B ? k : (B ? B - 1 : 0)));
       } else {
         b[u] = a.bits[blk];
       }
@@ -418,9 +429,12 @@ __global__ __launch_bounds__(BS) void k_unpack_fast(UnpackArgs a, uint32_t nwg =
       for (int u = 0; u < U; ++u) {
         const size_t blk = first + 2 * (size_t)u;
         const uint32_t last = b[u] ? b[u] - 1 : 0;
-        const u32x4 *in_payload = payload + (size_t)(o[u] >> 4) + ((uint32_t)k < last ? (uint32_t)k : last);
+        // stream layout: the record's width byte and the k width bytes before it sit in front of the payload
+        const uint64_t skip = a.stream_layout ? a.block_base + blk + 1 : 0;
+        const u32x4_u *in_payload = reinterpret_cast<const u32x4_u *>(
+            static_cast<const uint8_t *>(a.payload) + o[u] + skip + 16 * ((uint32_t)k < last ? (uint32_t)k : last));
         // a zero-width block has no payload: read (and ignore) its own output area instead
-        const u32x4 *in_output = reinterpret_cast<const u32x4 *>(a.out + blk * 128);
+        const u32x4_u *in_output = reinterpret_cast<const u32x4_u *>(a.out + blk * 128);
         src[u] = b[u] ? in_payload : in_output;
       }
     }
@@ -545,7 +559,7 @@ __global__ __launch_bounds__(BS) void k_pack_fast(PackArgs a) {
     const size_t tile = blockIdx.x;
     const size_t first = tile * per_iter + (size_t)wv * 2 * U + h;
     uint32_t b[U], seed[U];
-    size_t vbase[U];
+    uint8_t *pbase[U];
     u32x4 x[U], acc[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -553,10 +567,10 @@ __global__ __launch_bounds__(BS) void k_pack_fast(PackArgs a) {
       x[u] = stream_load(reinterpret_cast<const u32x4 *>(a.in + blk * 128 + 4 * k));
       if constexpr (B >= 0) {
         b[u] = B;
-        vbase[u] = blk * (size_t)B;
+        pbase[u] = reinterpret_cast<uint8_t *>(payload + blk * (size_t)B);
       } else {
         b[u] = a.bits[blk];
-        vbase[u] = (size_t)(a.off[blk] >> 4);
+        pbase[u] = static_cast<uint8_t *>(a.payload) + a.off[blk] + (a.stream_layout ? a.chain_base + blk + 1 : 0);
       }
       if constexpr (MODE == MODE_D1) {
         // explicit seeds, or chained from the input: block k starts from in[128k-1], block 0 from seed0
@@ -618,15 +632,16 @@ __global__ __launch_bounds__(BS) void k_pack_fast(PackArgs a) {
       const uint32_t bu = b[u];
       const uint32_t w = ((uint32_t)k * bu) >> 5;
       if constexpr (B == 32) {
-        payload[vbase[u] + k] = x[u];
+        *reinterpret_cast<u32x4 *>(pbase[u] + 16 * k) = x[u];
       } else if constexpr (B > 0) {
         const bool last = (k == 31) || ((((uint32_t)(k + 1) * bu) >> 5) != w);
-        if (last) payload[vbase[u] + w] = acc[u];
+        if (last) *reinterpret_cast<u32x4 *>(pbase[u] + 16 * w) = acc[u];
       } else if constexpr (B < 0) {
         const bool raw = bu == 32;
         const bool last = (k == 31) || ((((uint32_t)(k + 1) * bu) >> 5) != w);
         const u32x4 val = raw ? x[u] : acc[u];
-        if (bu != 0 && (raw || last)) payload[vbase[u] + w] = val;  // raw: w == k
+        if (bu != 0 && (raw || last)) *reinterpret_cast<u32x4_u *>(pbase[u] + 16 * w) = val;  // raw: w == k
+        if (a.stream_layout && k == 0) pbase[u][-1] = (uint8_t)bu;
       }
     }
     if constexpr (MODE == MODE_D1) {
@@ -962,6 +977,7 @@ hipError_t launch_unpack(int mode, bool tail, const UnpackArgs &a, hipStream_t s
     if (mixed) {
       r.bits += done;
       r.off += done;
+      r.block_base += done;
     } else {
       r.payload = static_cast<const uint8_t *>(r.payload) + done * 16 * (size_t)a.bit;
     }

@@ -39,9 +39,11 @@ int check_common(const void *ints, const void *payload, size_t nblocks, uint32_t
 
 int do_pack(int mode, int masked, uint32_t initvalue, const uint32_t *seeds, const uint32_t *in, void *payload,
             const uint64_t *off, const uint8_t *bits, uint32_t bit, size_t nblocks, uint32_t *seeds_out,
-            void *stream) {
+            void *stream, bool stream_layout = false) {
   const bool mixed = bits != nullptr;
-  if (int rc = check_common(in, payload, nblocks, mixed ? 0 : bit, mixed || bit != 0)) return rc;
+  // the byte stream has no alignment of its own: only the integer side is checked then
+  if (int rc = check_common(in, stream_layout ? in : payload, nblocks, mixed ? 0 : bit, mixed || bit != 0)) return rc;
+  if (stream_layout && nblocks && (!payload || !mixed)) return fail(SIMDCOMP_HIP_ENULL, "stream layout needs a stream and per-block widths");
   if (mixed && !off && nblocks) return fail(SIMDCOMP_HIP_ENULL, "per-block widths need per-block payload offsets");
   if (mode == SIMDCOMP_HIP_FOR && !seeds && mixed && nblocks)
     return fail(SIMDCOMP_HIP_ENULL, "frame bases are NULL");
@@ -57,15 +59,17 @@ int do_pack(int mode, int masked, uint32_t initvalue, const uint32_t *seeds, con
   a.bit = bit;
   a.seed0 = initvalue;
   a.carry_blocks = 0;
+  a.stream_layout = stream_layout ? 1u : 0u;
   return hip_result(sc::launch_pack(mode, masked != 0 && mode != SIMDCOMP_HIP_FOR, false, a,
                                     as_stream(stream)),
                     "pack launch");
 }
 
 int do_unpack(int mode, uint32_t seed0, const uint32_t *seeds, const void *payload, const uint64_t *off,
-              const uint8_t *bits, uint32_t bit, uint32_t *out, size_t nblocks, void *stream) {
+              const uint8_t *bits, uint32_t bit, uint32_t *out, size_t nblocks, void *stream, bool stream_layout = false) {
   const bool mixed = bits != nullptr;
-  if (int rc = check_common(out, payload, nblocks, mixed ? 0 : bit, mixed || bit != 0)) return rc;
+  if (int rc = check_common(out, stream_layout ? out : payload, nblocks, mixed ? 0 : bit, mixed || bit != 0)) return rc;
+  if (stream_layout && nblocks && (!payload || !mixed)) return fail(SIMDCOMP_HIP_ENULL, "stream layout needs a stream and per-block widths");
   if (mixed && !off && nblocks) return fail(SIMDCOMP_HIP_ENULL, "per-block widths need per-block payload offsets");
   sc::UnpackArgs a{};
   a.payload = payload;
@@ -77,6 +81,7 @@ int do_unpack(int mode, uint32_t seed0, const uint32_t *seeds, const void *paylo
   a.length = nblocks * 128;
   a.bit = bit;
   a.seed0 = seed0;
+  a.stream_layout = stream_layout ? 1u : 0u;
   return hip_result(sc::launch_unpack(mode, false, a, as_stream(stream)), "unpack launch");
 }
 
@@ -136,6 +141,24 @@ int simdcomp_hip_unpack_mixed(int mode, const uint32_t *d_initvalues, const void
   if (!d_bits && nblocks) return fail(SIMDCOMP_HIP_ENULL, "d_bits is NULL");
   if (mode != SIMDCOMP_HIP_PLAIN && !d_initvalues && nblocks) return fail(SIMDCOMP_HIP_ENULL, "d_initvalues is NULL");
   return do_unpack(mode, 0, d_initvalues, d_payload, d_payload_offsets, d_bits, 0, d_out, nblocks, stream);
+}
+
+int simdcomp_hip_pack_stream(int mode, int masked, uint32_t initvalue, const uint32_t *d_initvalues,
+                             const uint32_t *d_in, void *d_stream, const uint64_t *d_payload_offsets,
+                             const uint8_t *d_bits, size_t nblocks, uint32_t *d_initvalues_out, void *stream) {
+  if (mode < 0 || mode > 2) return fail(SIMDCOMP_HIP_EMODE, "unknown mode");
+  if (nblocks && (!d_bits || !d_payload_offsets)) return fail(SIMDCOMP_HIP_ENULL, "widths / offsets are NULL");
+  return do_pack(mode, masked, initvalue, d_initvalues, d_in, d_stream, d_payload_offsets, d_bits, 0, nblocks,
+                 d_initvalues_out, stream, true);
+}
+
+int simdcomp_hip_unpack_stream(int mode, const uint32_t *d_initvalues, const void *d_stream,
+                               const uint64_t *d_payload_offsets, const uint8_t *d_bits, uint32_t *d_out,
+                               size_t nblocks, void *stream) {
+  if (mode < 0 || mode > 2) return fail(SIMDCOMP_HIP_EMODE, "unknown mode");
+  if (nblocks && (!d_bits || !d_payload_offsets)) return fail(SIMDCOMP_HIP_ENULL, "widths / offsets are NULL");
+  if (mode != SIMDCOMP_HIP_PLAIN && !d_initvalues && nblocks) return fail(SIMDCOMP_HIP_ENULL, "d_initvalues is NULL");
+  return do_unpack(mode, 0, d_initvalues, d_stream, d_payload_offsets, d_bits, 0, d_out, nblocks, stream, true);
 }
 
 int simdcomp_hip_maxbits(const uint32_t *d_in, size_t nblocks, uint8_t *d_bits, void *stream) {
@@ -310,14 +333,15 @@ int simdcomp_hip_partition_by_bytes(const uint64_t *h_payload_offsets, size_t nb
 size_t simdcomp_hip_chain_workspace(size_t nblocks) { return sc::chain_workspace_bytes(nblocks); }
 
 int simdcomp_hip_chain_offsets(uint32_t initvalue, const void *d_payload, const uint64_t *d_payload_offsets,
-                               const uint8_t *d_bits, size_t nblocks, uint32_t *d_initvalues_out, void *d_workspace,
-                               void *stream) {
+                               const uint8_t *d_bits, size_t nblocks, int stream_layout, uint32_t *d_initvalues_out,
+                               void *d_workspace, void *stream) {
   if (nblocks == 0) return SIMDCOMP_HIP_OK;
   if (!d_payload || !d_payload_offsets || !d_bits || !d_initvalues_out || !d_workspace)
     return fail(SIMDCOMP_HIP_ENULL, "NULL pointer");
-  if (!aligned16(d_payload) || !aligned16(d_workspace)) return fail(SIMDCOMP_HIP_EALIGN, "pointer not 16-byte aligned");
-  return hip_result(sc::launch_chain_offsets(initvalue, d_payload, d_payload_offsets, d_bits, nblocks, d_initvalues_out,
-                                             d_workspace, as_stream(stream)),
+  if ((!stream_layout && !aligned16(d_payload)) || !aligned16(d_workspace))
+    return fail(SIMDCOMP_HIP_EALIGN, "pointer not 16-byte aligned");
+  return hip_result(sc::launch_chain_offsets(initvalue, d_payload, d_payload_offsets, d_bits, nblocks, stream_layout != 0,
+                                             d_initvalues_out, d_workspace, as_stream(stream)),
                     "chain offsets launch");
 }
 

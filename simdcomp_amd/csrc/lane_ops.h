@@ -7,6 +7,9 @@
 namespace sc {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// The same 16 bytes at any byte address: global memory runs in unaligned mode on this platform, so this is still one
+// global_load_dwordx4 / global_store_dwordx4 (tools/exp/unaligned_exp.hip checks it).  LDS accesses stay aligned.
+typedef u32x4 u32x4_u __attribute__((aligned(1)));
 
 constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118;
 constexpr int DPP_ROW_BCAST15 = 0x142;

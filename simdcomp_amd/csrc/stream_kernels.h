@@ -10,8 +10,9 @@ namespace sc {
 
 // --- chained d1 seeds: seed[0] = init, seed[k+1] = last value of block k ------------------------------------------
 size_t chain_workspace_bytes(size_t nblocks);
-hipError_t launch_chain_offsets(uint32_t init, const void *arena, const uint64_t *off, const uint8_t *bits, size_t nblocks,
-                                uint32_t *seeds_out, void *workspace, hipStream_t st);
+// stream_layout: `payload` is the byte stream (payload of block k at off[k] + k + 1), else the aligned arena
+hipError_t launch_chain_offsets(uint32_t init, const void *payload, const uint64_t *off, const uint8_t *bits, size_t nblocks,
+                                bool stream_layout, uint32_t *seeds_out, void *workspace, hipStream_t st);
 
 // --- [b][payload] byte stream <-> 16-byte aligned arena -----------------------------------------------------------
 // record k of the stream starts at byte off[k] + k (off[] = exclusive scan of 16*bits[])

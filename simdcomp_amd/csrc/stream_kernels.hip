@@ -23,35 +23,54 @@ namespace sc {
 // ---------------------------------------------------------------------------
 // sums[k] = sum of the 128 b-bit fields of block k (its deltas), or, for a
 // 32-bit block, its last raw value.  One block per half-wave, same extraction
-// as the decoder (wave-private LDS slot, funnel shift), nothing is stored but
-// one word per block.
-__global__ __launch_bounds__(256) void k_block_sums(const uint8_t *arena, const uint64_t *off, const uint8_t *bits,
-                                                    size_t nblocks, uint32_t *sums) {
+// as the decoder (wave-private LDS slot, funnel shift); nothing is stored but
+// one word per block, so a wave takes U blocks per half with all loads issued
+// up front to have enough bytes in flight.  Lanes past a payload's end re-read
+// its last vector; a zero-width block reads the first 16 bytes of `sums`.
+constexpr int SUMS_U = 4;
+
+__global__ __launch_bounds__(256) void k_block_sums(const uint8_t *payload, const uint64_t *off, const uint8_t *bits,
+                                                    size_t nblocks, uint32_t stream_layout, uint32_t *sums) {
   __shared__ u32x4 lds[4][2][33];
+  constexpr int U = SUMS_U;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int h = lane >> 5, k = lane & 31;
   u32x4 *slot = lds[wv][h];
-  const size_t blk = ((size_t)blockIdx.x * 4 + wv) * 2 + h;
-  const bool valid = blk < nblocks;
-  const size_t bc = valid ? blk : nblocks - 1;
-  uint32_t b = bits[bc];
-  b = b > 32 ? 32 : b;
-  const u32x4 *src = reinterpret_cast<const u32x4 *>(arena + off[bc]);
-  u32x4 ld = {0, 0, 0, 0};
-  if ((uint32_t)k < b) ld = src[k];
-  wave_lds_fence();
-  slot[k] = ld;
-  wave_lds_fence();
-  const uint32_t p = (uint32_t)k * b, w = p >> 5, s = p & 31;
-  const u32x4 lo = slot[w], hi = slot[w + 1];
-  const uint32_t m = field_mask(b);
-  u32x4 v;
-  v.x = funnel(hi.x, lo.x, s) & m;
-  v.y = funnel(hi.y, lo.y, s) & m;
-  v.z = funnel(hi.z, lo.z, s) & m;
-  v.w = funnel(hi.w, lo.w, s) & m;
-  const uint32_t total = half_scan_add(v.x + v.y + v.z + v.w);  // lane 31 of the half-wave: the block's sum
-  if (valid && k == 31) sums[blk] = b == 32 ? v.w : total;
+  const size_t first = ((size_t)blockIdx.x * 4 + wv) * 2 * U + h;
+  uint32_t b[U];
+  uint64_t o[U];
+  u32x4 ld[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const size_t blk = first + 2 * (size_t)u;
+    const size_t bc = blk < nblocks ? blk : nblocks - 1;
+    b[u] = bits[bc];
+    o[u] = off[bc] + (stream_layout ? bc + 1 : 0);
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    b[u] = b[u] > 32 ? 32 : b[u];
+    const uint32_t last = b[u] ? b[u] - 1 : 0;
+    const u32x4_u *in_payload = reinterpret_cast<const u32x4_u *>(payload + o[u] + 16 * ((uint32_t)k < last ? (uint32_t)k : last));
+    ld[u] = *(b[u] ? in_payload : reinterpret_cast<const u32x4_u *>(sums));
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const size_t blk = first + 2 * (size_t)u;
+    wave_lds_fence();
+    slot[k] = ld[u];
+    wave_lds_fence();
+    const uint32_t p = (uint32_t)k * b[u], w = p >> 5, s = p & 31;
+    const u32x4 lo = slot[w], hi = slot[w + 1];
+    const uint32_t m = field_mask(b[u]);
+    u32x4 v;
+    v.x = funnel(hi.x, lo.x, s) & m;
+    v.y = funnel(hi.y, lo.y, s) & m;
+    v.z = funnel(hi.z, lo.z, s) & m;
+    v.w = funnel(hi.w, lo.w, s) & m;
+    const uint32_t total = half_scan_add(v.x + v.y + v.z + v.w);  // lane 31 of the half-wave: the block's sum
+    if (blk < nblocks && k == 31) sums[blk] = b[u] == 32 ? v.w : total;
+  }
 }
 
 // (restart flag << 32) | value
@@ -125,16 +144,17 @@ size_t chain_workspace_bytes(size_t nblocks) {
   return align256(4 * nblocks) + align256(8 * ntiles) + align256(4 * ntiles) + 256;
 }
 
-hipError_t launch_chain_offsets(uint32_t init, const void *arena, const uint64_t *off, const uint8_t *bits, size_t nblocks,
-                                uint32_t *seeds_out, void *workspace, hipStream_t st) {
+hipError_t launch_chain_offsets(uint32_t init, const void *payload, const uint64_t *off, const uint8_t *bits, size_t nblocks,
+                                bool stream_layout, uint32_t *seeds_out, void *workspace, hipStream_t st) {
   if (nblocks == 0) return hipSuccess;
   const size_t ntiles = (nblocks + CHAIN_TILE - 1) / CHAIN_TILE;
   uint8_t *ws = static_cast<uint8_t *>(workspace);
   uint32_t *sums = reinterpret_cast<uint32_t *>(ws);
   uint64_t *tile_sum = reinterpret_cast<uint64_t *>(ws + align256(4 * nblocks));
   uint32_t *tile_in = reinterpret_cast<uint32_t *>(ws + align256(4 * nblocks) + align256(8 * ntiles));
-  hipLaunchKernelGGL(k_block_sums, dim3((unsigned)((nblocks + 7) / 8)), dim3(256), 0, st, static_cast<const uint8_t *>(arena), off,
-                     bits, nblocks, sums);
+  constexpr size_t per_wg = 8 * SUMS_U;
+  hipLaunchKernelGGL(k_block_sums, dim3((unsigned)((nblocks + per_wg - 1) / per_wg)), dim3(256), 0, st,
+                     static_cast<const uint8_t *>(payload), off, bits, nblocks, stream_layout ? 1u : 0u, sums);
   hipLaunchKernelGGL(k_chain_tiles, dim3((unsigned)ntiles), dim3(256), 0, st, bits, sums, nblocks, tile_sum);
   hipLaunchKernelGGL(k_chain_spine, dim3(1), dim3(256), 0, st, tile_sum, ntiles, init, tile_in);
   hipLaunchKernelGGL(k_chain_apply, dim3((unsigned)ntiles), dim3(256), 0, st, bits, sums, nblocks, tile_in, seeds_out);
@@ -144,81 +164,64 @@ hipError_t launch_chain_offsets(uint32_t init, const void *arena, const uint64_t
 // ---------------------------------------------------------------------------
 // [b][payload] stream <-> aligned arena
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t align_bytes(uint32_t hi, uint32_t lo, uint32_t nbytes) {
-  return __builtin_amdgcn_alignbyte(hi, lo, nbytes);  // ({hi,lo} >> 8*nbytes)[31:0]
-}
+// One block per half-wave, thread k < b moves payload vector k with one 16-byte load and one 16-byte store; the
+// stream side is at an arbitrary byte address.  U blocks per half-wave, loads first (clamped, never predicated),
+// stores after.  TO_STREAM also writes the width bytes.
+constexpr int COPY_U = 4;
 
-// One block per half-wave; thread k < b moves payload vector k.  The destination is at an arbitrary byte alignment:
-// bytes up to the next 4-byte boundary and after the last one go out as byte stores, the rest as aligned words.
-__global__ __launch_bounds__(256) void k_stream_build(const uint8_t *arena, const uint64_t *off, const uint8_t *bits, size_t nblocks,
-                                                      uint8_t *stream) {
+template <bool TO_STREAM>
+__global__ __launch_bounds__(256) void k_stream_copy(const uint8_t *src, uint8_t *dst, const uint64_t *off, const uint8_t *bits,
+                                                     size_t nblocks) {
+  constexpr int U = COPY_U;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int h = lane >> 5, k = lane & 31;
-  const size_t blk = ((size_t)blockIdx.x * 4 + wv) * 2 + h;
-  if (blk >= nblocks) return;
-  uint32_t b = bits[blk];
-  b = b > 32 ? 32 : b;
-  const uint64_t o = off[blk];
-  uint8_t *rec = stream + o + blk;
-  if (k == 0) rec[0] = (uint8_t)b;
-  if ((uint32_t)k >= b) return;
-  const u32x4 x = reinterpret_cast<const u32x4 *>(arena + o)[k];
-  uint8_t *d = rec + 1 + 16 * k;
-  const uint32_t m = (uint32_t)((uintptr_t)d & 3);
-  if (m == 0) {
-    uint32_t *q = reinterpret_cast<uint32_t *>(d);
-    q[0] = x.x;
-    q[1] = x.y;
-    q[2] = x.z;
-    q[3] = x.w;
-    return;
+  const size_t first = ((size_t)blockIdx.x * 4 + wv) * 2 * U + h;
+  uint32_t b[U];
+  uint64_t o[U];
+  u32x4 x[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const size_t blk = first + 2 * (size_t)u;
+    const size_t bc = blk < nblocks ? blk : nblocks - 1;
+    b[u] = bits[bc];
+    o[u] = off[bc];
   }
-  const uint32_t head = 4 - m;  // bytes before the first aligned word
-  for (uint32_t i = 0; i < head; ++i) d[i] = (uint8_t)(x.x >> (8 * i));
-  uint32_t *q = reinterpret_cast<uint32_t *>(d + head);
-  q[0] = align_bytes(x.y, x.x, head);
-  q[1] = align_bytes(x.z, x.y, head);
-  q[2] = align_bytes(x.w, x.z, head);
-  for (uint32_t i = 0; i < m; ++i) d[head + 12 + i] = (uint8_t)(x.w >> (8 * (head + i)));
-}
-
-// The inverse: five aligned words cover a payload vector that starts m bytes into the first of them.
-__global__ __launch_bounds__(256) void k_stream_unbuild(const uint8_t *stream, const uint64_t *off, const uint8_t *bits,
-                                                        size_t nblocks, uint8_t *arena) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int h = lane >> 5, k = lane & 31;
-  const size_t blk = ((size_t)blockIdx.x * 4 + wv) * 2 + h;
-  if (blk >= nblocks) return;
-  uint32_t b = bits[blk];
-  b = b > 32 ? 32 : b;
-  if ((uint32_t)k >= b) return;
-  const uint64_t o = off[blk];
-  const uint8_t *s = stream + o + blk + 1 + 16 * k;
-  const uint32_t m = (uint32_t)((uintptr_t)s & 3);
-  const uint32_t *q = reinterpret_cast<const uint32_t *>(s - m);
-  const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3];
-  const uint32_t d4 = m ? q[4] : 0;  // the word past the vector is only touched when it holds bytes of it
-  u32x4 x;
-  x.x = align_bytes(d1, d0, m);
-  x.y = align_bytes(d2, d1, m);
-  x.z = align_bytes(d3, d2, m);
-  x.w = align_bytes(d4, d3, m);
-  reinterpret_cast<u32x4 *>(arena + o)[k] = x;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const size_t blk = first + 2 * (size_t)u;
+    const size_t bc = blk < nblocks ? blk : nblocks - 1;
+    b[u] = b[u] > 32 ? 32 : b[u];
+    const uint32_t last = b[u] ? b[u] - 1 : 0;
+    const uint64_t from = o[u] + (TO_STREAM ? 0 : bc + 1) + 16 * ((uint32_t)k < last ? (uint32_t)k : last);
+    // a zero-width block has nothing to read
+    x[u] = u32x4{0, 0, 0, 0};
+    if (b[u]) x[u] = *reinterpret_cast<const u32x4_u *>(src + from);
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const size_t blk = first + 2 * (size_t)u;
+    if (blk >= nblocks) continue;
+    uint8_t *to = dst + o[u] + (TO_STREAM ? blk + 1 : 0);
+    if (TO_STREAM && k == 0) to[-1] = (uint8_t)b[u];
+    if ((uint32_t)k < b[u]) *reinterpret_cast<u32x4_u *>(to + 16 * k) = x[u];
+  }
 }
 
 hipError_t launch_stream_build(const void *arena, const uint64_t *off, const uint8_t *bits, size_t nblocks, uint8_t *stream,
                                hipStream_t st) {
   if (nblocks == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_stream_build, dim3((unsigned)((nblocks + 7) / 8)), dim3(256), 0, st, static_cast<const uint8_t *>(arena), off,
-                     bits, nblocks, stream);
+  constexpr size_t per_wg = 8 * COPY_U;
+  hipLaunchKernelGGL(k_stream_copy<true>, dim3((unsigned)((nblocks + per_wg - 1) / per_wg)), dim3(256), 0, st,
+                     static_cast<const uint8_t *>(arena), stream, off, bits, nblocks);
   return hipGetLastError();
 }
 
 hipError_t launch_stream_unbuild(const uint8_t *stream, const uint64_t *off, const uint8_t *bits, size_t nblocks, void *arena,
                                  hipStream_t st) {
   if (nblocks == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_stream_unbuild, dim3((unsigned)((nblocks + 7) / 8)), dim3(256), 0, st, stream, off, bits, nblocks,
-                     static_cast<uint8_t *>(arena));
+  constexpr size_t per_wg = 8 * COPY_U;
+  hipLaunchKernelGGL(k_stream_copy<false>, dim3((unsigned)((nblocks + per_wg - 1) / per_wg)), dim3(256), 0, st, stream,
+                     static_cast<uint8_t *>(arena), off, bits, nblocks);
   return hipGetLastError();
 }
 
@@ -242,36 +245,88 @@ constexpr uint32_t IDX_INVALID = 0xFFFFFFFFu;
 constexpr uint64_t IDX_INVALID64 = ~0ull;
 constexpr int IDX_BATCH = 2048;
 
-// Stage chunk c (len bytes from stream + c * IDX_CHUNK) in LDS as aligned words; returns the byte view of its start.
+// Stage len bytes from stream + c0 in LDS: whole 16-byte vectors (at whatever byte address they start), then the
+// last few bytes one by one so that nothing past the end of the stream is read.
 template <int THREADS>
-__device__ __forceinline__ const uint8_t *stage_chunk(const uint8_t *stream, size_t c0, uint32_t len, uint32_t *sh) {
-  const uintptr_t a0 = (uintptr_t)(stream + c0);
-  const uint32_t m = (uint32_t)(a0 & 3);
-  const uint32_t *q = reinterpret_cast<const uint32_t *>(a0 - m);
-  const uint32_t nwords = (m + len + 3) / 4;
-  for (uint32_t i = threadIdx.x; i < nwords; i += THREADS) sh[i] = q[i];
+__device__ __forceinline__ const uint8_t *stage_chunk(const uint8_t *stream, size_t c0, uint32_t len, u32x4 *sh) {
+  const uint8_t *src = stream + c0;
+  const uint32_t nvec = len / 16;
+  uint32_t i = threadIdx.x;
+  for (; i + 3 * THREADS < nvec; i += 4 * THREADS) {  // four loads in flight per thread
+    const u32x4 v0 = *reinterpret_cast<const u32x4_u *>(src + 16 * (size_t)i);
+    const u32x4 v1 = *reinterpret_cast<const u32x4_u *>(src + 16 * (size_t)(i + THREADS));
+    const u32x4 v2 = *reinterpret_cast<const u32x4_u *>(src + 16 * (size_t)(i + 2 * THREADS));
+    const u32x4 v3 = *reinterpret_cast<const u32x4_u *>(src + 16 * (size_t)(i + 3 * THREADS));
+    sh[i] = v0;
+    sh[i + THREADS] = v1;
+    sh[i + 2 * THREADS] = v2;
+    sh[i + 3 * THREADS] = v3;
+  }
+  for (; i < nvec; i += THREADS) sh[i] = *reinterpret_cast<const u32x4_u *>(src + 16 * (size_t)i);
+  uint8_t *bytes = reinterpret_cast<uint8_t *>(sh);
+  for (uint32_t j = 16 * nvec + threadIdx.x; j < len; j += THREADS) bytes[j] = src[j];
   __syncthreads();
-  return reinterpret_cast<const uint8_t *>(sh) + m;
+  return bytes;
 }
 
+// Kernel A.  Candidate f's walk goes through byte f + 1 + 16*b(f); when that is again one of the 513 candidates the
+// rest of the walk is that candidate's, so only "roots" (candidates whose first step already leaves the candidate
+// window) walk through the chunk; the others are linked to their successor and resolved by ten rounds of pointer
+// jumping over the 513 entries.  res[] words: (records << 16) | target, target < 1024: continue at that candidate,
+// target >= 1024: done, the walk left the chunk target - 1024 bytes into the next one.
+constexpr uint32_t IDX_DONE = 1024;
+
 __global__ __launch_bounds__(IDX_THREADS) void k_index_candidates(const uint8_t *stream, size_t nbytes, uint32_t *table) {
-  __shared__ uint32_t sh[IDX_CHUNK / 4 + 1];
+  __shared__ u32x4 sh[IDX_CHUNK / 16];
+  __shared__ uint32_t res[IDX_CAND];
   const size_t c0 = (size_t)blockIdx.x * IDX_CHUNK;
   const uint32_t len = (uint32_t)(nbytes - c0 < (size_t)IDX_CHUNK ? nbytes - c0 : (size_t)IDX_CHUNK);
   const uint8_t *by = stage_chunk<IDX_THREADS>(stream, c0, len, sh);
-  if (threadIdx.x >= IDX_CAND) return;
-  uint32_t p = threadIdx.x, cnt = 0;
-  bool bad = false;
-  while (p < len) {
-    const uint32_t b = by[p];
-    if (b > 32) {
-      bad = true;
-      break;
+  const uint32_t f = threadIdx.x;
+  if (f < IDX_CAND) {
+    uint32_t word;
+    if (f >= len) {
+      word = IDX_DONE + (f - len);  // the chunk is shorter than the candidate window
+    } else {
+      const uint32_t b = by[f];
+      const uint32_t nf = f + 1 + 16 * b;
+      if (b > 32) {
+        word = IDX_INVALID;
+      } else if (nf < IDX_CAND && nf < len) {
+        word = (1u << 16) | nf;
+      } else {
+        uint32_t p = nf, cnt = 1;
+        bool bad = false;
+        while (p < len) {
+          const uint32_t bb = by[p];
+          if (bb > 32) {
+            bad = true;
+            break;
+          }
+          p += 1 + 16 * bb;
+          ++cnt;
+        }
+        word = bad ? IDX_INVALID : ((cnt << 16) | (IDX_DONE + p - len));
+      }
     }
-    p += 1 + 16 * b;
-    ++cnt;
+    res[f] = word;
   }
-  table[(size_t)blockIdx.x * IDX_CAND + threadIdx.x] = bad ? IDX_INVALID : ((cnt << 16) | (p - len));
+  __syncthreads();
+  for (int round = 0; round < 10; ++round) {  // 2^10 >= the longest chain of links (513)
+    uint32_t w = f < IDX_CAND ? res[f] : IDX_INVALID;
+    const bool link = w != IDX_INVALID && (w & 0xFFFF) < IDX_DONE;
+    if (link) {
+      const uint32_t t = res[w & 0xFFFF];
+      w = t == IDX_INVALID ? IDX_INVALID : ((((w >> 16) + (t >> 16)) << 16) | (t & 0xFFFF));
+    }
+    __syncthreads();
+    if (link) res[f] = w;
+    __syncthreads();
+  }
+  if (f < IDX_CAND) {
+    const uint32_t w = res[f];
+    table[(size_t)blockIdx.x * IDX_CAND + f] = w == IDX_INVALID ? IDX_INVALID : (w - IDX_DONE);
+  }
 }
 
 __global__ __launch_bounds__(IDX_THREADS) void k_index_groups(const uint32_t *table, size_t nchunks, uint64_t *gtable) {
@@ -341,16 +396,20 @@ __global__ __launch_bounds__(64) void k_index_chunk_entries(const uint32_t *tabl
   }
 }
 
-__global__ __launch_bounds__(64) void k_index_emit(const uint8_t *stream, size_t nbytes, const uint64_t *centry, size_t max_blocks,
-                                                   uint8_t *bits, uint64_t *off) {
-  __shared__ uint32_t sh[IDX_CHUNK / 4 + 1];
+constexpr int EMIT_THREADS = 256;
+
+// Kernel E: the chunk is staged by the whole workgroup, one thread then follows the true chain (a dependent walk) and
+// leaves record positions in LDS in batches, which all threads write out coalesced.
+__global__ __launch_bounds__(EMIT_THREADS) void k_index_emit(const uint8_t *stream, size_t nbytes, const uint64_t *centry,
+                                                             size_t max_blocks, uint8_t *bits, uint64_t *off) {
+  __shared__ u32x4 sh[IDX_CHUNK / 16];
   __shared__ uint16_t plist[IDX_BATCH];
   __shared__ uint32_t s_p, s_n;
   const uint64_t ce = centry[blockIdx.x];
   if (ce == IDX_INVALID64) return;
   const size_t c0 = (size_t)blockIdx.x * IDX_CHUNK;
   const uint32_t len = (uint32_t)(nbytes - c0 < (size_t)IDX_CHUNK ? nbytes - c0 : (size_t)IDX_CHUNK);
-  const uint8_t *by = stage_chunk<64>(stream, c0, len, sh);
+  const uint8_t *by = stage_chunk<EMIT_THREADS>(stream, c0, len, sh);
   uint64_t base = ce >> 16;
   if (threadIdx.x == 0) s_p = (uint32_t)(ce & 0xFFFF);
   __syncthreads();
@@ -371,7 +430,7 @@ __global__ __launch_bounds__(64) void k_index_emit(const uint8_t *stream, size_t
     }
     __syncthreads();
     const uint32_t n = s_n;
-    for (uint32_t i = threadIdx.x; i < n; i += 64) {
+    for (uint32_t i = threadIdx.x; i < n; i += EMIT_THREADS) {
       const uint64_t r = base + i;
       if (r < max_blocks) {
         const uint32_t p = plist[i];
@@ -410,7 +469,7 @@ hipError_t launch_stream_index(const uint8_t *stream, size_t nbytes, size_t max_
   hipLaunchKernelGGL(k_index_spine, dim3(1), dim3(1), 0, st, gtable, ngroups, nbytes, gentry, result);
   hipLaunchKernelGGL(k_index_chunk_entries, dim3((unsigned)((ngroups + 63) / 64)), dim3(64), 0, st, table, nchunks, ngroups, gentry,
                      centry);
-  hipLaunchKernelGGL(k_index_emit, dim3((unsigned)nchunks), dim3(64), 0, st, stream, nbytes, centry, max_blocks, bits, off);
+  hipLaunchKernelGGL(k_index_emit, dim3((unsigned)nchunks), dim3(EMIT_THREADS), 0, st, stream, nbytes, centry, max_blocks, bits, off);
   return hipGetLastError();
 }
 

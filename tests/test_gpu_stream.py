@@ -75,6 +75,19 @@ def test_golden_stream_round_trip(dev, d1):
     else:
         out = dev.unpack_mixed(PLAIN, arena2, ibits, ioff, nblk)
     assert np.array_equal(u32(out), x)
+    # the same without the aligned arena: pack straight into a stream, decode straight from its bytes
+    import torch
+
+    direct = torch.full((want.size + 3,), 0xEE, dtype=torch.uint8, device="cuda")
+    dev.pack_stream(D1 if d1 else PLAIN, to_dev(x), bits, off, direct[3:], initvalues=seeds if d1 else None)
+    assert np.array_equal(direct[3:].cpu().numpy(), want) and (direct[:3] == 0xEE).all()
+    if d1:
+        chained = dev.chain_offsets(direct[3:], ibits, ioff, initvalue=0, stream_layout=True)
+        assert np.array_equal(u32(chained), u32(seeds))
+        out = dev.unpack_stream(D1, direct[3:], ibits, ioff, nblk, initvalues=chained)
+    else:
+        out = dev.unpack_stream(PLAIN, direct[3:], ibits, ioff, nblk)
+    assert np.array_equal(u32(out), x)
 
 
 @pytest.mark.parametrize("nblk", [1, 2, 9, 130, 4097, 70001])
@@ -104,6 +117,18 @@ def test_stream_sizes_and_alignments(dev, orc, nblk):
         got = arena2.cpu().numpy()
         assert np.array_equal(got[:nbytes], arena.cpu().numpy()[:nbytes])
         assert (got[nbytes:] == 0xCC).all(), "wrote outside the arena"
+        # in place: pack_stream (chained from the input, like example.c:63-71) and unpack_stream at this alignment
+        buf2 = torch.full((want.size + 16,), 0xDD, dtype=torch.uint8, device="cuda")
+        view2 = buf2[shift:shift + want.size]
+        dev.pack_stream(D1, to_dev(x), bits, off, view2, initvalue=0)
+        got = buf2.cpu().numpy()
+        assert np.array_equal(got[shift:shift + want.size], want)
+        assert (got[:shift] == 0xDD).all() and (got[shift + want.size:] == 0xDD).all(), "wrote outside the stream"
+        chained = dev.chain_offsets(view2, bits, off, initvalue=0, stream_layout=True)
+        assert np.array_equal(u32(chained), u32(seeds))
+        out = torch.full((nblk * 128 + 8,), 0x5A5A5A5A, dtype=torch.int32, device="cuda")
+        dev.unpack_stream(D1, view2, bits, off, nblk, initvalues=chained, out=out)
+        assert np.array_equal(u32(out[:nblk * 128]), x) and (out[nblk * 128:] == 0x5A5A5A5A).all()
     for init in (0, 0xDEADBEEF):
         # offsets chained from another start value: decode equals the CPU loop of example.c:101-110
         chained = dev.chain_offsets(arena, bits, off, initvalue=init)
@@ -175,4 +200,12 @@ def test_large_stream_2p27(dev):
     chained = dev.chain_offsets(arena2, ibits, ioff, initvalue=0)
     assert torch.equal(chained, seeds)
     out = dev.unpack_mixed(D1, arena2, ibits, ioff, nblk, initvalues=chained)
+    assert int(dev.checksum(out, other=ids)[1].item()) == 0
+    # and in place, with no arena at all
+    stream2 = torch.empty_like(stream)
+    dev.pack_stream(D1, ids, bits, off, stream2, initvalue=0)
+    assert torch.equal(stream2, stream)
+    chained = dev.chain_offsets(stream2, ibits, ioff, initvalue=0, stream_layout=True)
+    assert torch.equal(chained, seeds)
+    out = dev.unpack_stream(D1, stream2, ibits, ioff, nblk, initvalues=chained)
     assert int(dev.checksum(out, other=ids)[1].item()) == 0

@@ -15,7 +15,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-from simdcomp_amd import codec  # noqa: E402
+from simdcomp_amd import binding, codec  # noqa: E402
 
 PEAK = 8.0e12
 
@@ -67,6 +67,86 @@ def mixed(n, nblk, ints, out, reps):
     print("mixed", json.dumps(res), flush=True)
 
 
+def stream(n, nblk, reps):
+    """The example.c byte stream on the device (widths 0..20 skewed small, 2 % of the blocks 32-bit):
+    build, record index, unbuild, chained offsets; next to the CPU decode loop of example.c:101-110."""
+    import numpy as np
+
+    dev = torch.device("cuda:0")
+    w = torch.minimum(torch.randint(0, 21, (nblk,), device=dev), torch.randint(0, 21, (nblk,), device=dev))
+    gaps = torch.randint(0, 1 << 30, (n,), dtype=torch.int32, device=dev)
+    gaps &= ((1 << w) - 1).to(torch.int32).repeat_interleave(128)
+    ids = torch.cumsum(gaps, 0, dtype=torch.int32)
+    del gaps
+    wild = torch.randint(0, nblk, (nblk // 50,), device=dev)
+    ids.view(-1, 128)[wild] = torch.randint(-2 ** 31, 2 ** 31 - 1, (wild.numel(), 128), dtype=torch.int32, device=dev)
+    seeds = torch.empty(nblk, dtype=torch.int32, device=dev)
+    bits = codec.maxbitsd1(ids, initvalue=0, initvalues_out=seeds)
+    off, total = codec.payload_offsets(bits)
+    T = int(total.item())
+    arena = torch.empty(T + 16, dtype=torch.uint8, device=dev)
+    codec.pack_mixed(1, ids, bits, off, arena, initvalues=seeds)
+    strm = codec.stream_build(arena, bits, off, T)
+    ibits, ioff, res = codec.stream_index(strm, nblk)
+    assert res.tolist() == [nblk, T, 0] and torch.equal(ibits, bits) and torch.equal(ioff, off)
+    arena2 = codec.stream_unbuild(strm, bits, off, T)
+    chained = codec.chain_offsets(strm, bits, off, stream_layout=True)
+    assert torch.equal(chained, seeds) and torch.equal(arena2[:T], arena[:T])
+    strm2 = torch.empty_like(strm)
+    codec.pack_stream(1, ids, bits, off, strm2, initvalue=0)
+    assert torch.equal(strm2, strm)
+    out = torch.empty_like(ids)
+    ws_i = torch.empty(binding.lib().simdcomp_hip_stream_index_workspace(T + nblk), dtype=torch.uint8, device=dev)
+    ws_c = torch.empty(binding.lib().simdcomp_hip_chain_workspace(nblk), dtype=torch.uint8, device=dev)
+    r3 = torch.empty(3, dtype=torch.int64, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    L, P = binding.lib(), binding.ptr
+    rows = {
+        "stream_build": (lambda: L.simdcomp_hip_stream_build(P(arena), P(off), P(bits), nblk, P(strm), st), 2 * T + 10 * nblk),
+        "stream_index": (lambda: L.simdcomp_hip_stream_index(P(strm), T + nblk, nblk, P(ibits), P(ioff), P(r3), P(ws_i), st),
+                         T + 10 * nblk),
+        "stream_unbuild": (lambda: L.simdcomp_hip_stream_unbuild(P(strm), P(off), P(bits), nblk, P(arena2), st), 2 * T + 10 * nblk),
+        "chain_offsets": (lambda: L.simdcomp_hip_chain_offsets(0, P(strm), P(off), P(bits), nblk, 1, P(chained), P(ws_c), st),
+                          T + 14 * nblk),
+        "unpack_stream": (lambda: codec.unpack_stream(1, strm, bits, off, nblk, initvalues=seeds, out=out), 512 * nblk + T + 14 * nblk),
+        "unpack_mixed": (lambda: codec.unpack_mixed(1, arena, bits, off, nblk, initvalues=seeds, out=out), 512 * nblk + T + 13 * nblk),
+        "pack_stream": (lambda: codec.pack_stream(1, ids, bits, off, strm2, initvalue=0), 512 * nblk + T + 10 * nblk),
+        "maxbitsd1": (lambda: codec.maxbitsd1(ids, initvalue=0, initvalues_out=seeds), 517 * nblk),
+        "payload_offsets": (lambda: codec.payload_offsets(bits), 9 * nblk),
+    }
+    res = {"avg_bits": round(T / nblk / 16, 2), "stream_MiB": round((T + nblk) / 2 ** 20, 1)}
+    for name, (f, by) in rows.items():
+        t = timeit(f, reps)
+        res[name] = {"ms": round(t * 1e3, 4), "Gint/s": round(n / t / 1e9, 1), "GB/s": round(by / t / 1e9, 1), "frac": round(by / t / PEAK, 3)}
+    whole = sum(res[k]["ms"] for k in ("stream_index", "chain_offsets", "unpack_stream")) * 1e-3
+    res["decode_from_stream_bytes"] = {"ms": round(whole * 1e3, 4), "Gint/s": round(n / whole / 1e9, 1),
+                                       "what": "stream_index + chain_offsets + unpack_stream (example.c:101-110)"}
+    whole = sum(res[k]["ms"] for k in ("maxbitsd1", "payload_offsets", "pack_stream")) * 1e-3
+    res["compress_to_stream"] = {"ms": round(whole * 1e3, 4), "Gint/s": round(n / whole / 1e9, 1),
+                                 "what": "maxbitsd1 + payload_offsets + pack_stream (example.c:56-75)"}
+    try:
+        import oracle
+
+        orc = oracle.Oracle()
+        ref = oracle.Reference() if oracle.have_ref() else orc
+        m = min(nblk, 1 << 19)  # 2^26 integers
+        cut = int(off[m].item()) + m if m < nblk else T + nblk
+        h = strm[:cut].cpu().numpy()
+        best = 1e9
+        import time
+
+        for _ in range(3):
+            t0 = time.perf_counter()
+            dec = orc.stream_decode(h, m, d1=True, codec=ref)
+            best = min(best, time.perf_counter() - t0)
+        assert np.array_equal(dec.view(np.int32), ids[: m * 128].cpu().numpy())
+        res["cpu_stream_decode"] = {"Gint/s": round(m * 128 / best / 1e9, 2), "cores": 1, "ints": m * 128,
+                                    "kind": "reference" if oracle.have_ref() else "port"}
+    except Exception as e:  # pragma: no cover
+        res["cpu_stream_decode"] = str(e)
+    print("stream", json.dumps(res), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--log2n", type=int, default=28)
@@ -93,7 +173,7 @@ def main():
             res["read(sum)"] = {"GB/s": 4 * n / t / 1e9}
             print(json.dumps(res), flush=True)
             continue
-        if what == "mixed":
+        if what in ("mixed", "stream"):
             continue
         row = {}
         for b in bits:
@@ -125,6 +205,10 @@ def main():
         print(what, json.dumps(row), flush=True)
     if "mixed" in a.what.split(","):
         mixed(n, nblk, ints, out, a.reps)
+    if "stream" in a.what.split(","):
+        del ints, out, payload
+        torch.cuda.empty_cache()
+        stream(n, nblk, a.reps)
 
 
 if __name__ == "__main__":
