@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsimdcomp_hip.so")
+# SIMDCOMP_HIP_LIB names another build of the same library (A/B runs of kernel variants)
+LIB_PATH = os.environ.get("SIMDCOMP_HIP_LIB") or os.path.join(_HERE, "libsimdcomp_hip.so")
 
 u32, u64, vp, sz = C.c_uint32, C.c_uint64, C.c_void_p, C.c_size_t
 

@@ -237,13 +237,16 @@ hipError_t launch_stream_unbuild(const uint8_t *stream, const uint64_t *off, con
 //      and first record number;  D  one thread per group does the same for its chunks;
 //   E  every chunk walks its true chain once more and writes width and arena offset of each record.
 // A width byte above 32 ends a walk as invalid; the true chain hitting one is reported in result[2].
-constexpr int IDX_CHUNK = 32768;
+#ifndef SC_IDX_CHUNK
+#define SC_IDX_CHUNK 16384
+#endif
+constexpr int IDX_CHUNK = SC_IDX_CHUNK;
 constexpr int IDX_CAND = 513;
-constexpr int IDX_THREADS = 576;
+constexpr int IDX_THREADS = 256;
 constexpr int IDX_GROUP = 256;
 constexpr uint32_t IDX_INVALID = 0xFFFFFFFFu;
 constexpr uint64_t IDX_INVALID64 = ~0ull;
-constexpr int IDX_BATCH = 2048;
+constexpr int IDX_BATCH = 1024;
 
 // Stage len bytes from stream + c0 in LDS: whole 16-byte vectors (at whatever byte address they start), then the
 // last few bytes one by one so that nothing past the end of the stream is read.
@@ -279,11 +282,13 @@ constexpr uint32_t IDX_DONE = 1024;
 __global__ __launch_bounds__(IDX_THREADS) void k_index_candidates(const uint8_t *stream, size_t nbytes, uint32_t *table) {
   __shared__ u32x4 sh[IDX_CHUNK / 16];
   __shared__ uint32_t res[IDX_CAND];
+  __shared__ uint16_t roots[IDX_CAND];
+  __shared__ uint32_t nroots;
   const size_t c0 = (size_t)blockIdx.x * IDX_CHUNK;
   const uint32_t len = (uint32_t)(nbytes - c0 < (size_t)IDX_CHUNK ? nbytes - c0 : (size_t)IDX_CHUNK);
+  if (threadIdx.x == 0) nroots = 0;
   const uint8_t *by = stage_chunk<IDX_THREADS>(stream, c0, len, sh);
-  const uint32_t f = threadIdx.x;
-  if (f < IDX_CAND) {
+  for (uint32_t f = threadIdx.x; f < IDX_CAND; f += IDX_THREADS) {
     uint32_t word;
     if (f >= len) {
       word = IDX_DONE + (f - len);  // the chunk is shorter than the candidate window
@@ -295,41 +300,59 @@ __global__ __launch_bounds__(IDX_THREADS) void k_index_candidates(const uint8_t 
       } else if (nf < IDX_CAND && nf < len) {
         word = (1u << 16) | nf;
       } else {
-        uint32_t p = nf, cnt = 1;
-        bool bad = false;
-        while (p < len) {
-          const uint32_t bb = by[p];
-          if (bb > 32) {
-            bad = true;
-            break;
-          }
-          p += 1 + 16 * bb;
-          ++cnt;
-        }
-        word = bad ? IDX_INVALID : ((cnt << 16) | (IDX_DONE + p - len));
+        word = IDX_INVALID;  // replaced by the walk below
+        roots[atomicAdd(&nroots, 1u)] = (uint16_t)f;
       }
     }
     res[f] = word;
   }
   __syncthreads();
+  // the roots, packed into the first threads so that the other waves do not sit in the loop
+  for (uint32_t t = threadIdx.x; t < nroots; t += IDX_THREADS) {
+    const uint32_t r = roots[t];
+    uint32_t p = r + 1 + 16 * (uint32_t)by[r], cnt = 1;
+    bool bad = false;
+    while (p < len) {
+      const uint32_t bb = by[p];
+      if (bb > 32) {
+        bad = true;
+        break;
+      }
+      p += 1 + 16 * bb;
+      ++cnt;
+    }
+    res[r] = bad ? IDX_INVALID : ((cnt << 16) | (IDX_DONE + p - len));
+  }
+  __syncthreads();
+  constexpr int PER_THREAD = (IDX_CAND + IDX_THREADS - 1) / IDX_THREADS;
   for (int round = 0; round < 10; ++round) {  // 2^10 >= the longest chain of links (513)
-    uint32_t w = f < IDX_CAND ? res[f] : IDX_INVALID;
-    const bool link = w != IDX_INVALID && (w & 0xFFFF) < IDX_DONE;
-    if (link) {
-      const uint32_t t = res[w & 0xFFFF];
-      w = t == IDX_INVALID ? IDX_INVALID : ((((w >> 16) + (t >> 16)) << 16) | (t & 0xFFFF));
+    uint32_t w[PER_THREAD];
+    bool link[PER_THREAD];
+#pragma unroll
+    for (int i = 0; i < PER_THREAD; ++i) {
+      const uint32_t f = threadIdx.x + i * IDX_THREADS;
+      w[i] = f < IDX_CAND ? res[f] : IDX_INVALID;
+      link[i] = w[i] != IDX_INVALID && (w[i] & 0xFFFF) < IDX_DONE;
+      if (link[i]) {
+        const uint32_t t = res[w[i] & 0xFFFF];
+        w[i] = t == IDX_INVALID ? IDX_INVALID : ((((w[i] >> 16) + (t >> 16)) << 16) | (t & 0xFFFF));
+      }
     }
     __syncthreads();
-    if (link) res[f] = w;
+#pragma unroll
+    for (int i = 0; i < PER_THREAD; ++i)
+      if (link[i]) res[threadIdx.x + i * IDX_THREADS] = w[i];
     __syncthreads();
   }
-  if (f < IDX_CAND) {
+  for (uint32_t f = threadIdx.x; f < IDX_CAND; f += IDX_THREADS) {
     const uint32_t w = res[f];
     table[(size_t)blockIdx.x * IDX_CAND + f] = w == IDX_INVALID ? IDX_INVALID : (w - IDX_DONE);
   }
 }
 
-__global__ __launch_bounds__(IDX_THREADS) void k_index_groups(const uint32_t *table, size_t nchunks, uint64_t *gtable) {
+constexpr int GROUP_THREADS = 576;  // one thread per candidate (513), whole waves
+
+__global__ __launch_bounds__(GROUP_THREADS) void k_index_groups(const uint32_t *table, size_t nchunks, uint64_t *gtable) {
   if (threadIdx.x >= IDX_CAND) return;
   const size_t cbeg = (size_t)blockIdx.x * IDX_GROUP;
   const size_t cend = cbeg + IDX_GROUP < nchunks ? cbeg + IDX_GROUP : nchunks;
@@ -465,7 +488,7 @@ hipError_t launch_stream_index(const uint8_t *stream, size_t nbytes, size_t max_
   ws += align256(8 * ngroups);
   uint64_t *centry = reinterpret_cast<uint64_t *>(ws);
   hipLaunchKernelGGL(k_index_candidates, dim3((unsigned)nchunks), dim3(IDX_THREADS), 0, st, stream, nbytes, table);
-  hipLaunchKernelGGL(k_index_groups, dim3((unsigned)ngroups), dim3(IDX_THREADS), 0, st, table, nchunks, gtable);
+  hipLaunchKernelGGL(k_index_groups, dim3((unsigned)ngroups), dim3(GROUP_THREADS), 0, st, table, nchunks, gtable);
   hipLaunchKernelGGL(k_index_spine, dim3(1), dim3(1), 0, st, gtable, ngroups, nbytes, gentry, result);
   hipLaunchKernelGGL(k_index_chunk_entries, dim3((unsigned)((ngroups + 63) / 64)), dim3(64), 0, st, table, nchunks, ngroups, gentry,
                      centry);
