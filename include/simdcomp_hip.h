@@ -193,6 +193,43 @@ size_t simdcomp_hip_stream_index_workspace(size_t stream_bytes);
 int simdcomp_hip_stream_index(const void *d_stream, size_t stream_bytes, size_t max_blocks, uint8_t *d_bits,
                               uint64_t *d_payload_offsets, uint64_t *d_result, void *d_workspace, void *stream);
 
+/* ---- batched random access: many queries per launch -------------------------- */
+
+/* Blocks are addressed like everywhere else: uniform width (d_bits = NULL, block k
+ * at k*16*bit) or per-block widths with d_payload_offsets (stream_layout = 1: the
+ * byte stream above); d_initvalues = per-block d1 offset / FOR base (NULL: the
+ * scalar `initvalue` for every block).  Query q addresses block d_query_blocks[q]
+ * (NULL: block q).  mode: SIMDCOMP_HIP_D1, SIMDCOMP_HIP_FOR, or
+ * SIMDCOMP_HIP_PLAIN (= FOR with base 0).
+ *
+ * select: d_values_out[q] = value number d_slots[q] of its block --
+ *   simdselectd1 (src/simdpackedselect.c:8096, slot taken mod 128) /
+ *   simdselectFOR (src/simdfor.c:14987). */
+int simdcomp_hip_select(int mode, uint32_t initvalue, const uint32_t *d_initvalues, const void *d_payload,
+                        const uint64_t *d_payload_offsets, const uint8_t *d_bits, uint32_t bit, int stream_layout,
+                        const uint64_t *d_query_blocks, const int32_t *d_slots, size_t nqueries,
+                        uint32_t *d_values_out, void *stream);
+/* search: position and value of the first of the first d_lengths[q] (NULL: 128)
+ * values of the block that is >= d_keys[q] --
+ *   D1: simdsearchwithlengthd1 (src/simdpackedsearch.c:8284): not found gives
+ *       (length, key + 1); a 32-bit block is bisected as the reference does.
+ *       d_last4_out (optional, 4 words per query): the offset vector simdsearchd1
+ *       (:16583) leaves behind when called with all four elements = the offset.
+ *   FOR / PLAIN: simdsearchwithlengthFOR (src/simdfor.c:15016): lower-bound
+ *       bisection; the value at the returned slot is reported even when it is
+ *       below the key (0 when the slot is 128, where the reference reads past
+ *       the block).  d_last4_out must be NULL. */
+int simdcomp_hip_search(int mode, uint32_t initvalue, const uint32_t *d_initvalues, const void *d_payload,
+                        const uint64_t *d_payload_offsets, const uint8_t *d_bits, uint32_t bit, int stream_layout,
+                        const uint64_t *d_query_blocks, const uint32_t *d_keys, const int32_t *d_lengths,
+                        size_t nqueries, int32_t *d_positions_out, uint32_t *d_values_out, uint32_t *d_last4_out,
+                        void *stream);
+/* scan: d_last4_out[4k..4k+3] = the last four values of block k -- what
+ * simdscand1 (src/simdpackedselect.c:15216) leaves in its offset vector. */
+int simdcomp_hip_scand1(uint32_t initvalue, const uint32_t *d_initvalues, const void *d_payload,
+                        const uint64_t *d_payload_offsets, const uint8_t *d_bits, uint32_t bit, int stream_layout,
+                        size_t nblocks, uint32_t *d_last4_out, void *stream);
+
 /* ---- block-range partitioner and verification reduction -------------------- */
 
 /* Contiguous block range of shard `part` out of `nparts`: blocks are

@@ -87,6 +87,10 @@ class BlockCodec:
         self._unpackFOR_length = fn("simdunpackFOR_length", vp, [u32, vp, C.c_int, vp, u32])
         self._selectFOR = fn("simdselectFOR", u32, [u32, vp, u32, C.c_int])
         self._searchFOR = fn("simdsearchwithlengthFOR", C.c_int, [u32, vp, u32, C.c_int, u32, vp])
+        self._selectd1 = fn("simdselectd1", u32, [u32, vp, u32, C.c_int])
+        self._searchlend1 = fn("simdsearchwithlengthd1", C.c_int, [u32, vp, u32, C.c_int, u32, vp])
+        self._searchd1 = fn("simdsearchd1", C.c_int, [vp, vp, u32, u32, vp])
+        self._scand1 = fn("simdscand1", None, [vp, vp, u32])
         self._fastset = fn("simdfastset", None, [vp, u32, u32, C.c_size_t])
         self._fastsetFOR = fn("simdfastsetFOR", None, [u32, vp, u32, u32, C.c_size_t])
 
@@ -229,6 +233,35 @@ class BlockCodec:
         pos = self._searchFOR(int(base), _ptr(c), bit, length, int(key), C.byref(r))
         return int(pos), r.value
 
+    @staticmethod
+    def _block512(comp):
+        """The payload in a 16-byte aligned 512-byte buffer (the search routines read whole vectors of a 32-bit block)."""
+        c = aligned_empty(512 + 64, np.uint8)
+        c[:] = 0
+        comp = np.asarray(comp, np.uint8)
+        c[:comp.size] = comp
+        return c
+
+    def simdselectd1(self, init, comp, bit, slot):
+        return int(self._selectd1(int(init), _ptr(self._block512(comp)), bit, slot))
+
+    def simdsearchwithlengthd1(self, init, comp, bit, length, key):
+        r = u32()
+        pos = self._searchlend1(int(init), _ptr(self._block512(comp)), bit, length, int(key), C.byref(r))
+        return int(pos), r.value
+
+    def simdsearchd1(self, offset4, comp, bit, key):
+        """-> (position, value, offset vector after the call)"""
+        o = aligned_copy(np.asarray(offset4, np.uint32))
+        r = u32()
+        pos = self._searchd1(_ptr(o), _ptr(self._block512(comp)), bit, int(key), C.byref(r))
+        return int(pos), r.value, o.copy()
+
+    def simdscand1(self, offset4, comp, bit):
+        o = aligned_copy(np.asarray(offset4, np.uint32))
+        self._scand1(_ptr(o), _ptr(self._block512(comp)), bit)
+        return o.copy()
+
     def simdfastset(self, comp, bit, value, index):
         c = np.asarray(comp, np.uint8).copy()
         self._fastset(_ptr(c), bit, int(value), index)
@@ -283,6 +316,8 @@ class Oracle(BlockCodec):
         L.stream_decode_d1.argtypes = [vp, vp, C.c_size_t, u32, vp]
         L.stream_decode_plain.restype = None
         L.stream_decode_plain.argtypes = [vp, vp, C.c_size_t, vp]
+        L.query_search_time.restype = C.c_double
+        L.query_search_time.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp, vp, C.c_int]
         L.stream_walk.restype = C.c_size_t
         L.stream_walk.argtypes = [vp, C.c_size_t, C.c_size_t, vp, vp, vp]
 
@@ -363,6 +398,16 @@ class Oracle(BlockCodec):
         status = C.c_int(0)
         n = self.lib.stream_walk(_ptr(stream), stream.size, max_blocks, _ptr(bits), _ptr(off), C.byref(status))
         return int(n), bits, off, status.value
+
+    def time_search(self, seeds, payload, off, bits, query_blocks, keys, reps=3, codec=None):
+        """One simdsearchwithlengthd1 call per query on one core -> (seconds, positions, values)."""
+        codec = codec or self
+        nq = keys.size
+        pos = np.zeros(nq, np.int32)
+        val = np.zeros(nq, np.uint32)
+        t = self.lib.query_search_time(C.cast(codec._searchlend1, vp), _ptr(seeds), _ptr(payload), _ptr(off), _ptr(bits),
+                                       _ptr(query_blocks), _ptr(keys), nq, _ptr(pos), _ptr(val), reps)
+        return float(t), pos, val
 
     def time_blocks(self, kind, fn_ptr, seeds, payload, ints, bit, nblocks, nthreads, reps):
         """Best-of-reps wall seconds for one pass; kind 0 unpack seeded, 1 unpack plain,

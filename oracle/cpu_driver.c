@@ -185,3 +185,26 @@ size_t stream_walk(const uint8_t *buffer, size_t nbytes, size_t max_blocks, uint
   if (p != nbytes) *status = 1;
   return k;
 }
+
+/* ---- batched search on the CPU: the reference's simdsearchwithlengthd1 (or the
+ * restatement's) called once per query, for timing next to the device batch.
+ * Returns the best wall time of `reps` passes; results go to pos[] / val[]. */
+typedef int (*searchlen_fn)(uint32_t, const void *, uint32_t, int, uint32_t, uint32_t *);
+
+double query_search_time(void *fn, const uint32_t *seeds, const uint8_t *payload, const uint64_t *off, const uint8_t *bits,
+                         const uint64_t *query_blocks, const uint32_t *keys, size_t nq, int32_t *pos, uint32_t *val,
+                         int reps) {
+  double best = 1e30;
+  int r;
+  size_t q;
+  for (r = -1; r < reps; ++r) {
+    double t0 = now_s(), dt;
+    for (q = 0; q < nq; ++q) {
+      size_t k = (size_t)query_blocks[q];
+      pos[q] = ((searchlen_fn)fn)(seeds[k], payload + off[k], bits[k], 128, keys[q], &val[q]);
+    }
+    dt = now_s() - t0;
+    if (r >= 0 && dt < best) best = dt;
+  }
+  return best;
+}

@@ -422,6 +422,107 @@ int orc_simdsearchwithlengthFOR(uint32_t initvalue, const void *in, uint32_t bit
   return lo;
 }
 
+/* src/simdpackedselect.c:8096 simdselectd1(): the slot-th value of the
+ * differentially coded block; the slot is reduced mod 128 (":8100 slot &= 127"),
+ * a 0-bit block yields the offset, widths above 32 yield (uint32_t)-1 (:8239). */
+uint32_t orc_simdselectd1(uint32_t initvalue, const void *in, uint32_t bit, int slot) {
+  uint32_t tmp[ORC_BLOCK];
+  if (bit > 32) return (uint32_t)-1;
+  orc_simdunpackd1(initvalue, in, tmp, bit);
+  return tmp[slot & 127];
+}
+
+/* The bisection the reference uses on raw 32-bit blocks
+ * (src/simdpackedsearch.c:29 lower_bound): not std::lower_bound on unsorted
+ * input, so it is restated step for step. */
+static int ref_lower_bound(const uint32_t *a, uint32_t key, int imin, int imax) {
+  imax--;
+  while (imin + 1 < imax) {
+    int imid = imin + (imax - imin) / 2;
+    if (a[imid] >= key)
+      imax = imid;
+    else
+      imin = imid;
+  }
+  return a[imin] >= key ? imin : imax;
+}
+
+/* src/simdpackedsearch.c:8284 simdsearchwithlengthd1(): position of the first
+ * of the first `length` decoded values that is >= key (unsigned), its value in
+ * *presult; `length` and key + 1 when there is none.  Widths 1..31 scan four
+ * values at a time (:58-73), which amounts to a linear scan; width 0 tests the
+ * offset once (:76-89); width 32 bisects the raw values (:8270-8282).  The
+ * reference reads in32[-1] for width 32 with length 0; here that case is "not found". */
+int orc_simdsearchwithlengthd1(uint32_t initvalue, const void *in, uint32_t bit, int length, uint32_t key,
+                               uint32_t *presult) {
+  uint32_t tmp[ORC_BLOCK];
+  int i;
+  if (bit > 32) return -1;
+  if (bit == 32) {
+    const uint32_t *raw = (const uint32_t *)in;
+    int answer;
+    if (length <= 0) {
+      *presult = key + 1;
+      return length;
+    }
+    answer = ref_lower_bound(raw, key, 0, length);
+    if (raw[answer] < key) {
+      *presult = key + 1;
+      return length;
+    }
+    *presult = raw[answer];
+    return answer;
+  }
+  if (bit == 0) {
+    if (length > 0 && initvalue >= key) {
+      *presult = initvalue;
+      return 0;
+    }
+    *presult = key + 1;
+    return length;
+  }
+  orc_simdunpackd1(initvalue, in, tmp, bit);
+  for (i = 0; i < length && i < (int)ORC_BLOCK; ++i) {
+    if (tmp[i] >= key) {
+      *presult = tmp[i];
+      return i;
+    }
+  }
+  *presult = key + 1;
+  return length;
+}
+
+/* src/simdpackedsearch.c:16583 simdsearchd1(): the same over all 128 values,
+ * with the running offset kept as a vector of the last four decoded values
+ * that the caller carries from block to block: on return it holds the group of
+ * four in which the search stopped (the last group when nothing was found);
+ * width 0 leaves it alone (:8410-8420), width 32 loads the block's last vector
+ * only when the key was found (:16570-16581).  Only element 3 seeds the block. */
+int orc_simdsearchd1(uint32_t offset4[4], const void *in, uint32_t bit, uint32_t key, uint32_t *presult) {
+  uint32_t tmp[ORC_BLOCK];
+  int pos, g;
+  if (bit > 32) return -1;
+  pos = orc_simdsearchwithlengthd1(offset4[3], in, bit, (int)ORC_BLOCK, key, presult);
+  if (bit == 0) return pos;
+  if (bit == 32) {
+    if (pos < (int)ORC_BLOCK) memcpy(offset4, (const uint32_t *)in + 124, 16);
+    return pos;
+  }
+  orc_simdunpackd1(offset4[3], in, tmp, bit);
+  g = pos < (int)ORC_BLOCK ? pos / 4 : 31;
+  memcpy(offset4, tmp + 4 * g, 16);
+  return pos;
+}
+
+/* src/simdpackedselect.c:15216 simdscand1(): walks the block and leaves its last
+ * four values in the offset vector (width 0: untouched). */
+void orc_simdscand1(uint32_t offset4[4], const void *in, uint32_t bit) {
+  uint32_t tmp[ORC_BLOCK];
+  if (bit == 0 || bit > 32) return;
+  orc_simdunpackd1(offset4[3], in, tmp, bit);
+  memcpy(offset4, tmp + 124, 16);
+}
+
 /* src/simdbitpacking.c:14338 simdfastset(): overwrite one field in place.  The
  * low part is cleared with the b-bit mask and the raw value ORed in; the
  * spill word has its low (s + b - 32) bits replaced by value >> (32 - s). */

@@ -40,6 +40,9 @@ DEVICE_API = {
     "simdcomp_hip_stream_unbuild": (C.c_int, [vp, vp, vp, sz, vp, vp]),
     "simdcomp_hip_stream_index_workspace": (sz, [sz]),
     "simdcomp_hip_stream_index": (C.c_int, [vp, sz, sz, vp, vp, vp, vp, vp]),
+    "simdcomp_hip_select": (C.c_int, [C.c_int, u32, vp, vp, vp, vp, u32, C.c_int, vp, vp, sz, vp, vp]),
+    "simdcomp_hip_search": (C.c_int, [C.c_int, u32, vp, vp, vp, vp, u32, C.c_int, vp, vp, vp, sz, vp, vp, vp, vp]),
+    "simdcomp_hip_scand1": (C.c_int, [u32, vp, vp, vp, vp, u32, C.c_int, sz, vp, vp]),
     "simdcomp_hip_compressedbytes": (sz, [sz, u32]),
     "simdcomp_hip_pack_length": (C.c_int, [vp, sz, vp, u32, vp]),
     "simdcomp_hip_unpack_length": (C.c_int, [vp, sz, vp, u32, vp]),

@@ -208,6 +208,38 @@ def stream_index(stream, max_blocks, nbytes=None):
     return bits, off, res
 
 
+def select(mode, payload, slots, bit=0, bits=None, offsets=None, initvalues=None, initvalue=0, query_blocks=None,
+           stream_layout=False):
+    """Batched simdselectd1 / simdselectFOR: slots int32[nq] -> values int32[nq]."""
+    nq = slots.numel()
+    out = torch.empty(nq, dtype=torch.int32, device=slots.device)
+    B.check(B.lib().simdcomp_hip_select(mode, _s32(initvalue), B.ptr(initvalues), B.ptr(payload), B.ptr(offsets),
+                                        B.ptr(bits), bit, int(stream_layout), B.ptr(query_blocks), B.ptr(slots), nq,
+                                        B.ptr(out), _stream()), "select")
+    return out
+
+
+def search(mode, payload, keys, bit=0, bits=None, offsets=None, initvalues=None, initvalue=0, query_blocks=None,
+           lengths=None, stream_layout=False, want_last4=False):
+    """Batched simdsearchwithlengthd1 / simdsearchwithlengthFOR -> (positions int32[nq], values int32[nq][, last4])."""
+    nq = keys.numel()
+    pos = torch.empty(nq, dtype=torch.int32, device=keys.device)
+    val = torch.empty(nq, dtype=torch.int32, device=keys.device)
+    last4 = torch.empty(nq * 4, dtype=torch.int32, device=keys.device) if want_last4 else None
+    B.check(B.lib().simdcomp_hip_search(mode, _s32(initvalue), B.ptr(initvalues), B.ptr(payload), B.ptr(offsets),
+                                        B.ptr(bits), bit, int(stream_layout), B.ptr(query_blocks), B.ptr(keys),
+                                        B.ptr(lengths), nq, B.ptr(pos), B.ptr(val), B.ptr(last4), _stream()), "search")
+    return (pos, val, last4) if want_last4 else (pos, val)
+
+
+def scand1(payload, nblocks, bit=0, bits=None, offsets=None, initvalues=None, initvalue=0, stream_layout=False):
+    """Batched simdscand1: the last four values of every block, int32[nblocks*4]."""
+    out = torch.empty(nblocks * 4, dtype=torch.int32, device=payload.device)
+    B.check(B.lib().simdcomp_hip_scand1(_s32(initvalue), B.ptr(initvalues), B.ptr(payload), B.ptr(offsets), B.ptr(bits),
+                                        bit, int(stream_layout), nblocks, B.ptr(out), _stream()), "scand1")
+    return out
+
+
 def pack_length(x, bit, out=None):
     x = _i32(x)
     n = x.numel()

@@ -8,6 +8,7 @@
 #include "../../include/simdcomp_hip.h"
 #include "codec_kernels.h"
 #include "stream_kernels.h"
+#include "query_kernels.h"
 
 namespace {
 
@@ -376,6 +377,72 @@ int simdcomp_hip_stream_index(const void *d_stream, size_t stream_bytes, size_t 
   return hip_result(sc::launch_stream_index(static_cast<const uint8_t *>(d_stream), stream_bytes, max_blocks, d_bits,
                                             d_payload_offsets, d_result, d_workspace, as_stream(stream)),
                     "stream index launch");
+}
+
+namespace {
+int do_query(int mode, int what, uint32_t initvalue, const uint32_t *d_initvalues, const void *d_payload,
+             const uint64_t *d_payload_offsets, const uint8_t *d_bits, uint32_t bit, int stream_layout, sc::QueryArgs a,
+             void *stream) {
+  if (mode < 0 || mode > 2) return fail(SIMDCOMP_HIP_EMODE, "unknown mode");
+  if (a.nqueries == 0) return SIMDCOMP_HIP_OK;
+  if (!d_bits && bit > 32) return fail(SIMDCOMP_HIP_EBIT, "bit width > 32");
+  if (!d_payload && (d_bits || bit)) return fail(SIMDCOMP_HIP_ENULL, "payload pointer is NULL");
+  if (d_bits && !d_payload_offsets) return fail(SIMDCOMP_HIP_ENULL, "per-block widths need per-block payload offsets");
+  if (stream_layout && !d_bits) return fail(SIMDCOMP_HIP_ENULL, "stream layout needs per-block widths");
+  if (!stream_layout && !aligned16(d_payload)) return fail(SIMDCOMP_HIP_EALIGN, "payload not 16-byte aligned");
+  a.payload = d_payload;
+  a.off = d_bits ? d_payload_offsets : nullptr;
+  a.bits = d_bits;
+  a.seeds = d_initvalues;
+  a.bit = bit;
+  a.seed0 = initvalue;
+  a.stream_layout = stream_layout ? 1u : 0u;
+  return hip_result(sc::launch_query(mode, what, a, as_stream(stream)), "query launch");
+}
+}  // namespace
+
+int simdcomp_hip_select(int mode, uint32_t initvalue, const uint32_t *d_initvalues, const void *d_payload,
+                        const uint64_t *d_payload_offsets, const uint8_t *d_bits, uint32_t bit, int stream_layout,
+                        const uint64_t *d_query_blocks, const int32_t *d_slots, size_t nqueries,
+                        uint32_t *d_values_out, void *stream) {
+  if (nqueries && (!d_slots || !d_values_out)) return fail(SIMDCOMP_HIP_ENULL, "NULL pointer");
+  sc::QueryArgs a{};
+  a.query_blocks = d_query_blocks;
+  a.slots = d_slots;
+  a.nqueries = nqueries;
+  a.values_out = d_values_out;
+  return do_query(mode, sc::Q_SELECT, initvalue, d_initvalues, d_payload, d_payload_offsets, d_bits, bit, stream_layout, a,
+                  stream);
+}
+
+int simdcomp_hip_search(int mode, uint32_t initvalue, const uint32_t *d_initvalues, const void *d_payload,
+                        const uint64_t *d_payload_offsets, const uint8_t *d_bits, uint32_t bit, int stream_layout,
+                        const uint64_t *d_query_blocks, const uint32_t *d_keys, const int32_t *d_lengths,
+                        size_t nqueries, int32_t *d_positions_out, uint32_t *d_values_out, uint32_t *d_last4_out,
+                        void *stream) {
+  if (nqueries && (!d_keys || !d_values_out || !d_positions_out)) return fail(SIMDCOMP_HIP_ENULL, "NULL pointer");
+  if (d_last4_out && mode != SIMDCOMP_HIP_D1) return fail(SIMDCOMP_HIP_EMODE, "the offset vector exists for d1 only");
+  sc::QueryArgs a{};
+  a.query_blocks = d_query_blocks;
+  a.keys = d_keys;
+  a.lengths = d_lengths;
+  a.nqueries = nqueries;
+  a.values_out = d_values_out;
+  a.positions_out = d_positions_out;
+  a.last4_out = d_last4_out;
+  return do_query(mode, sc::Q_SEARCH, initvalue, d_initvalues, d_payload, d_payload_offsets, d_bits, bit, stream_layout, a,
+                  stream);
+}
+
+int simdcomp_hip_scand1(uint32_t initvalue, const uint32_t *d_initvalues, const void *d_payload,
+                        const uint64_t *d_payload_offsets, const uint8_t *d_bits, uint32_t bit, int stream_layout,
+                        size_t nblocks, uint32_t *d_last4_out, void *stream) {
+  if (nblocks && !d_last4_out) return fail(SIMDCOMP_HIP_ENULL, "NULL pointer");
+  sc::QueryArgs a{};
+  a.nqueries = nblocks;
+  a.last4_out = d_last4_out;
+  return do_query(SIMDCOMP_HIP_D1, sc::Q_SCAN, initvalue, d_initvalues, d_payload, d_payload_offsets, d_bits, bit,
+                  stream_layout, a, stream);
 }
 
 int simdcomp_hip_checksum(const uint32_t *d_data, const uint32_t *d_other, size_t nwords, uint64_t index0,

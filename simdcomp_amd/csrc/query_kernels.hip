@@ -1,0 +1,190 @@
+// Batched select / search / scan over packed blocks (gfx950 / CDNA4).
+//
+// One query per 32-lane half of a wave64.  The half-wave decodes its block the
+// way the decoder does (payload vectors into a wave-private LDS slot, funnel
+// shift, DPP prefix sum for d1), leaves the 128 values in a second LDS slot and
+// answers from there, so a query costs one read of 16*b bytes and writes 4-24
+// bytes.  The answers follow the reference routine by routine, including what
+// it does on unsorted input:
+//   simdselectd1            src/simdpackedselect.c:8096  (slot & 127, 0-bit block = offset)
+//   simdsearchwithlengthd1  src/simdpackedsearch.c:8284  (widths 1..31 and 0: first of the first
+//                           `length` values >= key, else length and key+1; width 32: the bisection of :29)
+//   simdsearchd1, simdscand1  :16583, src/simdpackedselect.c:15216 (the four values left in the offset vector)
+//   simdselectFOR, simdsearchwithlengthFOR  src/simdfor.c:14987, :15016 (lower-bound bisection, value at the
+//                           returned slot even when nothing was found)
+#include "query_kernels.h"
+
+#include "codec_kernels.h"
+#include "lane_ops.h"
+
+namespace sc {
+
+__device__ __forceinline__ uint32_t half_ballot(bool c, int h) {
+  return (uint32_t)(__ballot(c) >> (32 * h));
+}
+
+// Queries per half-wave.  Taking several per half-wave (their three dependent fetches -- block number, then width /
+// offset / seed, then payload -- issued together) measured SLOWER than one (3.0 against 5.0 G queries/s at 4): the
+// fetches sit behind per-query branches, and the extra registers cost occupancy, which is what hides their latency.
+constexpr int QUERY_U = 1;
+
+template <int MODE, int WHAT>
+__global__ __launch_bounds__(256) void k_query(QueryArgs a) {
+  __shared__ u32x4 lds_pay[4][2][33];
+  __shared__ u32x4 lds_val[4][2][32];
+  constexpr int U = QUERY_U;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int h = lane >> 5, k = lane & 31;
+  u32x4 *slot = lds_pay[wv][h];
+  u32x4 *vals4 = lds_val[wv][h];
+  const uint32_t *vals = reinterpret_cast<const uint32_t *>(vals4);
+  const size_t first = ((size_t)blockIdx.x * 4 + wv) * 2 * U + h;
+  size_t qcs[U], blks[U];
+  uint32_t bs[U], seeds[U];
+  const uint8_t *pbases[U];
+  u32x4 lds_in[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const size_t q = first + 2 * (size_t)u;
+    qcs[u] = q < a.nqueries ? q : a.nqueries - 1;
+    blks[u] = a.query_blocks ? a.query_blocks[qcs[u]] : qcs[u];
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    bs[u] = a.bits ? a.bits[blks[u]] : a.bit;
+    pbases[u] = static_cast<const uint8_t *>(a.payload);
+    if (a.off) pbases[u] += a.off[blks[u]] + (a.stream_layout ? blks[u] + 1 : 0);
+    seeds[u] = MODE == MODE_PLAIN ? 0u : (a.seeds ? a.seeds[blks[u]] : a.seed0);
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    bs[u] = bs[u] > 32 ? 32 : bs[u];
+    if (!a.off) pbases[u] += blks[u] * 16 * (size_t)bs[u];
+    lds_in[u] = u32x4{0, 0, 0, 0};
+    if ((uint32_t)k < bs[u]) lds_in[u] = *reinterpret_cast<const u32x4_u *>(pbases[u] + 16 * k);
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+  const size_t q = first + 2 * (size_t)u;
+  const bool valid = q < a.nqueries;
+  const size_t qc = qcs[u];
+  const uint32_t b = bs[u];
+  const uint32_t seed = seeds[u];
+  wave_lds_fence();
+  slot[k] = lds_in[u];
+  wave_lds_fence();
+  const uint32_t p = (uint32_t)k * b, w = p >> 5, s = p & 31;
+  const u32x4 lo = slot[w], hi = slot[w + 1];
+  const uint32_t m = field_mask(b);
+  u32x4 v;
+  v.x = funnel(hi.x, lo.x, s) & m;
+  v.y = funnel(hi.y, lo.y, s) & m;
+  v.z = funnel(hi.z, lo.z, s) & m;
+  v.w = funnel(hi.w, lo.w, s) & m;
+  if (b < 32) {
+    if constexpr (MODE == MODE_D1) {
+      v.y += v.x;
+      v.z += v.y;
+      v.w += v.z;
+      const uint32_t before = seed + half_scan_add(v.w) - v.w;
+      v += before;
+    } else {
+      v += seed;
+    }
+  }
+  wave_lds_fence();
+  vals4[k] = v;
+  wave_lds_fence();
+
+  if constexpr (WHAT == Q_SELECT) {
+    const uint32_t at = (uint32_t)a.slots[qc] & 127u;
+    if (valid && k == 0) a.values_out[q] = vals[at];
+  } else if constexpr (WHAT == Q_SCAN) {
+    if (valid && k == 31) *reinterpret_cast<u32x4_u *>(a.last4_out + 4 * q) = v;
+  } else {
+    const uint32_t key = a.keys[qc];
+    int length = a.lengths ? a.lengths[qc] : 128;
+    length = length < 0 ? 0 : (length > 128 ? 128 : length);
+    int pos;
+    uint32_t value;
+    if constexpr (MODE == MODE_D1) {
+      bool found;
+      if (b == 32) {
+        // raw values, bisected exactly as src/simdpackedsearch.c:29 does
+        int imin = 0, imax = length - 1;
+        while (imin + 1 < imax) {
+          const int imid = imin + (imax - imin) / 2;
+          if (vals[imid] >= key) imax = imid;
+          else imin = imid;
+        }
+        pos = (length > 0 && vals[imin] >= key) ? imin : imax;
+        found = length > 0 && vals[pos] >= key;
+      } else {
+        const uint32_t base = 4 * (uint32_t)k;
+        const uint32_t m0 = half_ballot((int)base + 0 < length && v.x >= key, h);
+        const uint32_t m1 = half_ballot((int)base + 1 < length && v.y >= key, h);
+        const uint32_t m2 = half_ballot((int)base + 2 < length && v.z >= key, h);
+        const uint32_t m3 = half_ballot((int)base + 3 < length && v.w >= key, h);
+        pos = 128;
+        if (m0) pos = min(pos, 4 * __builtin_ctz(m0) + 0);
+        if (m1) pos = min(pos, 4 * __builtin_ctz(m1) + 1);
+        if (m2) pos = min(pos, 4 * __builtin_ctz(m2) + 2);
+        if (m3) pos = min(pos, 4 * __builtin_ctz(m3) + 3);
+        found = pos < 128;
+      }
+      value = found ? vals[pos & 127] : key + 1;
+      pos = found ? pos : length;
+      if (a.last4_out) {
+        // what simdsearchd1 leaves in its offset vector (meaningful for length 128)
+        u32x4 last = {seed, seed, seed, seed};
+        if (b == 32) {
+          if (found) last = vals4[31];
+        } else if (b != 0) {
+          last = vals4[found ? pos >> 2 : 31];
+        }
+        if (valid && k == 0) *reinterpret_cast<u32x4_u *>(a.last4_out + 4 * q) = last;
+      }
+    } else {
+      int begin = 0, count = length;
+      while (count > 0) {
+        const int step = count / 2;
+        if (vals[begin + step] < key) {
+          begin += step + 1;
+          count -= step + 1;
+        } else {
+          count = step;
+        }
+      }
+      pos = begin;
+      value = begin < 128 ? vals[begin] : 0u;  // the reference reads past the block here
+    }
+    if (valid && k == 0) {
+      a.positions_out[q] = pos;
+      a.values_out[q] = value;
+    }
+  }
+  }
+}
+
+hipError_t launch_query(int mode, int what, const QueryArgs &a, hipStream_t st) {
+  if (a.nqueries == 0) return hipSuccess;
+  const dim3 g((unsigned)((a.nqueries + 8 * QUERY_U - 1) / (8 * QUERY_U))), t(256);
+#define SC_Q(MODE_, WHAT_) hipLaunchKernelGGL((k_query<MODE_, WHAT_>), g, t, 0, st, a)
+  if (mode == MODE_D1) {
+    if (what == Q_SELECT) SC_Q(MODE_D1, Q_SELECT);
+    else if (what == Q_SEARCH) SC_Q(MODE_D1, Q_SEARCH);
+    else SC_Q(MODE_D1, Q_SCAN);
+  } else if (mode == MODE_FOR) {
+    if (what == Q_SELECT) SC_Q(MODE_FOR, Q_SELECT);
+    else if (what == Q_SEARCH) SC_Q(MODE_FOR, Q_SEARCH);
+    else return hipErrorInvalidValue;
+  } else {
+    if (what == Q_SELECT) SC_Q(MODE_PLAIN, Q_SELECT);
+    else if (what == Q_SEARCH) SC_Q(MODE_PLAIN, Q_SEARCH);
+    else return hipErrorInvalidValue;
+  }
+#undef SC_Q
+  return hipGetLastError();
+}
+
+}  // namespace sc

@@ -61,3 +61,24 @@ def stream_corpus(seed, nblk):
     wild[:, 1::2] &= np.uint32(0x7FFFFFFF)  # alternate high/low so that successive differences need all 32 bits
     v[kind == 1] = wild[kind == 1]
     return np.ascontiguousarray(v.reshape(-1))
+
+
+QUERY_LENGTHS = [128, 127, 65, 4, 3, 1]
+QUERY_SLOTS = [0, 1, 2, 3, 4, 63, 64, 126, 127, 133]
+
+
+def query_block(bit, kind):
+    """One block for the select / search fixtures: kind 0 sorted with gaps below 2^bit,
+    kind 1 arbitrary 32-bit values (unsorted: exercises what the reference's searches do then)."""
+    init = 990 + bit
+    if bit == 0:
+        return np.full(128, init, np.uint32), init
+    if kind == 0:
+        return synth.sorted_gaps(800 + bit, 128, min(bit, 25), first=init), init
+    return synth.rand_u32(850 + bit, 128), init
+
+
+def query_keys(dec, bit, kind):
+    extra = synth.rand_u32(870 + 2 * bit + kind, 4)
+    ks = [0, 1, int(dec[0]), int(dec[5]), int(dec[64]) + 1, int(dec[127]), int(dec[127]) + 1, 0xFFFFFFFF, 0x80000000]
+    return np.array([k & 0xFFFFFFFF for k in ks] + [int(e) for e in extra], dtype=np.uint32)

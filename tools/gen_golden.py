@@ -22,6 +22,9 @@ Files written
   stream.npz    the [width byte][payload] byte streams of example.c:56-75 (d1)
                 and :135-150 (plain) over 600 blocks that include 0-bit and
                 32-bit blocks, written by the reference's block routines
+  queries.npz   simdselectd1 / simdsearchwithlengthd1 / simdsearchd1 / simdscand1
+                and simdselectFOR / simdsearchwithlengthFOR answers of the
+                reference on sorted and unsorted blocks of every width
 """
 import os
 import sys
@@ -174,6 +177,38 @@ def gen_stream(ref):
     np.savez_compressed(os.path.join(OUT, "stream.npz"), nblocks=np.uint64(nblk), d1=d1, plain=plain)
 
 
+def gen_queries(ref):
+    """simdselectd1 / simdsearchwithlengthd1 / simdsearchd1 / simdscand1 and the FOR select / search of the
+    reference on one block per width and kind."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import golden_util as G
+
+    nk, nl, ns = 13, len(G.QUERY_LENGTHS), len(G.QUERY_SLOTS)
+    sel = np.zeros((33, 2, 2, ns), np.uint32)            # [bit][kind][d1, FOR][slot]
+    srch = np.zeros((33, 2, 2, nk, nl, 2), np.int64)      # [bit][kind][d1, FOR][key][length](pos, value)
+    full = np.zeros((33, 2, nk, 6), np.int64)             # simdsearchd1: pos, value, offset vector after
+    scan = np.zeros((33, 2, 4), np.uint32)
+    for bit in range(33):
+        for kind in range(2):
+            x, init = G.query_block(bit, kind)
+            d1 = ref.simdpackwithoutmaskd1(init, x, bit)
+            fr = ref.simdpackFOR(init, x, bit)
+            dec = ref.simdunpackd1(init, d1, bit)
+            keys = G.query_keys(dec, bit, kind)
+            for i, slot in enumerate(G.QUERY_SLOTS):
+                sel[bit, kind, 0, i] = ref.simdselectd1(init, d1, bit, slot)
+                sel[bit, kind, 1, i] = ref.simdselectFOR(init, fr, bit, slot & 127)
+            for ki, key in enumerate(keys):
+                for li, length in enumerate(G.QUERY_LENGTHS):
+                    srch[bit, kind, 0, ki, li] = ref.simdsearchwithlengthd1(init, d1, bit, length, int(key))
+                    # the reference reads slot `length` when nothing is found: stay inside the block
+                    srch[bit, kind, 1, ki, li] = ref.simdsearchwithlengthFOR(init, fr, bit, min(length, 127), int(key))
+                pos, val, o4 = ref.simdsearchd1(np.full(4, init, np.uint32), d1, bit, int(key))
+                full[bit, kind, ki] = [pos, val] + [int(v) for v in o4]
+            scan[bit, kind] = ref.simdscand1(np.full(4, init, np.uint32), d1, bit)
+    np.savez_compressed(os.path.join(OUT, "queries.npz"), select=sel, search=srch, searchd1=full, scan=scan)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     ORC = oracle.Oracle()  # used only for its FNV helper
@@ -182,5 +217,6 @@ if __name__ == "__main__":
     gen_lengths(REF)
     gen_corpus(REF)
     gen_stream(REF)
+    gen_queries(REF)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -147,6 +147,54 @@ def stream(n, nblk, reps):
     print("stream", json.dumps(res), flush=True)
 
 
+def query(n, nblk, reps):
+    """Batched search / select over a mixed-width d1 corpus: random block per query and one query per block,
+    next to the reference's simdsearchwithlengthd1 called per query on one core."""
+    import numpy as np
+
+    dev = torch.device("cuda:0")
+    w = torch.minimum(torch.randint(1, 21, (nblk,), device=dev), torch.randint(1, 21, (nblk,), device=dev))
+    gaps = torch.randint(0, 1 << 30, (n,), dtype=torch.int32, device=dev)
+    gaps &= ((1 << w) - 1).to(torch.int32).repeat_interleave(128)
+    ids = torch.cumsum(gaps, 0, dtype=torch.int32)
+    del gaps
+    seeds = torch.empty(nblk, dtype=torch.int32, device=dev)
+    bits = codec.maxbitsd1(ids, initvalue=0, initvalues_out=seeds)
+    off, total = codec.payload_offsets(bits)
+    T = int(total.item())
+    arena = torch.empty(T + 16, dtype=torch.uint8, device=dev)
+    codec.pack_mixed(1, ids, bits, off, arena, initvalues=seeds)
+    res = {"blocks": nblk, "avg_bits": round(T / nblk / 16, 2)}
+    for name, nq, qb in (("random_blocks", 1 << 24, torch.randint(0, nblk, (1 << 24,), device=dev)),
+                         ("every_block", nblk, None)):
+        blk = qb if qb is not None else torch.arange(nblk, device=dev)
+        keys = ids.view(-1, 128)[blk, torch.randint(0, 128, (nq,), device=dev)] + 1
+        slots = torch.randint(0, 128, (nq,), dtype=torch.int32, device=dev)
+        pos, val = codec.search(1, arena, keys, bits=bits, offsets=off, initvalues=seeds, query_blocks=qb)
+        t = timeit(lambda: codec.search(1, arena, keys, bits=bits, offsets=off, initvalues=seeds, query_blocks=qb), reps)
+        by = float((16 * bits[blk].long()).sum().item()) + nq * (13 + 8 + 4 + 8)
+        res["search_" + name] = {"queries": nq, "ms": round(t * 1e3, 4), "Gquery/s": round(nq / t / 1e9, 2), "GB/s": round(by / t / 1e9, 1)}
+        t = timeit(lambda: codec.select(1, arena, slots, bits=bits, offsets=off, initvalues=seeds, query_blocks=qb), reps)
+        res["select_" + name] = {"queries": nq, "ms": round(t * 1e3, 4), "Gquery/s": round(nq / t / 1e9, 2)}
+        if qb is not None:
+            try:
+                import oracle
+
+                orc = oracle.Oracle()
+                ref = oracle.Reference() if oracle.have_ref() else orc
+                m = 1 << 20
+                h_pay = np.concatenate([arena.cpu().numpy(), np.zeros(512, np.uint8)])
+                tt, hp, hv = orc.time_search(seeds.cpu().numpy().view(np.uint32), h_pay, off.cpu().numpy().view(np.uint64),
+                                             bits.cpu().numpy(), qb[:m].cpu().numpy().view(np.uint64),
+                                             keys[:m].cpu().numpy().view(np.uint32), codec=ref)
+                assert np.array_equal(hp, pos[:m].cpu().numpy()) and np.array_equal(hv, val[:m].cpu().numpy().view(np.uint32))
+                res["cpu_search_random_blocks"] = {"queries": m, "Mquery/s": round(m / tt / 1e6, 2), "cores": 1,
+                                                   "kind": "reference" if oracle.have_ref() else "port"}
+            except Exception as e:  # pragma: no cover
+                res["cpu_search_random_blocks"] = str(e)
+    print("query", json.dumps(res), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--log2n", type=int, default=28)
@@ -173,7 +221,7 @@ def main():
             res["read(sum)"] = {"GB/s": 4 * n / t / 1e9}
             print(json.dumps(res), flush=True)
             continue
-        if what in ("mixed", "stream"):
+        if what in ("mixed", "stream", "query"):
             continue
         row = {}
         for b in bits:
@@ -205,6 +253,8 @@ def main():
         print(what, json.dumps(row), flush=True)
     if "mixed" in a.what.split(","):
         mixed(n, nblk, ints, out, a.reps)
+    if "query" in a.what.split(","):
+        query(n, nblk, a.reps)
     if "stream" in a.what.split(","):
         del ints, out, payload
         torch.cuda.empty_cache()
