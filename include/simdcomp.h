@@ -61,6 +61,15 @@ void simdfastset(__m128i *in128, uint32_t b, uint32_t value, size_t index);     
 void simdpackd1(uint32_t initvalue, const uint32_t *in, __m128i *out, const uint32_t bit);            /* :24 */
 void simdpackwithoutmaskd1(uint32_t initvalue, const uint32_t *in, __m128i *out, const uint32_t bit); /* :30 */
 void simdunpackd1(uint32_t initvalue, const __m128i *in, uint32_t *out, const uint32_t bit);          /* :34 */
+/* single-block accessors (host routines; batched device forms: simdcomp_hip_select / _search / _scand1) */
+int simdsearchd1(__m128i *initOffset, const __m128i *in, uint32_t bit, uint32_t key, uint32_t *presult); /* :45 */
+int simdsearchwithlengthd1(uint32_t initvalue, const __m128i *in, uint32_t bit, int length, uint32_t key,
+                           uint32_t *presult);                                                         /* :57 */
+uint32_t simdselectd1(uint32_t initvalue, const __m128i *in, uint32_t bit, int slot);                  /* :62 */
+void simdfastsetd1fromprevious(__m128i *in, uint32_t bit, uint32_t previousvalue, uint32_t value,
+                               size_t index);                                                          /* :71 */
+void simdfastsetd1(uint32_t initvalue, __m128i *in, uint32_t bit, uint32_t value, size_t index);      /* :81 */
+void simdscand1(__m128i *initOffset, const __m128i *in, uint32_t bit);                                 /* :90 */
 
 /* ---- include/simdfor.h ------------------------------------------------------ */
 void simdpackFOR(uint32_t initvalue, const uint32_t *in, __m128i *out, const uint32_t bit);   /* :20 */

@@ -80,6 +80,12 @@ HOST_API = {
     "simdpackFOR_compressedbytes": (C.c_int, [C.c_int, u32]),
     "simdpackFOR_length": (vp, [u32, vp, C.c_int, vp, u32]),
     "simdunpackFOR_length": (vp, [u32, vp, C.c_int, vp, u32]),
+    "simdselectd1": (u32, [u32, vp, u32, C.c_int]),
+    "simdsearchwithlengthd1": (C.c_int, [u32, vp, u32, C.c_int, u32, vp]),
+    "simdsearchd1": (C.c_int, [vp, vp, u32, u32, vp]),
+    "simdscand1": (None, [vp, vp, u32]),
+    "simdfastsetd1": (None, [u32, vp, u32, u32, sz]),
+    "simdfastsetd1fromprevious": (None, [vp, u32, u32, u32, sz]),
     "simdselectFOR": (u32, [u32, vp, u32, C.c_int]),
     "simdfastsetFOR": (None, [u32, vp, u32, u32, sz]),
     "simdsearchwithlengthFOR": (C.c_int, [u32, vp, u32, C.c_int, u32, vp]),

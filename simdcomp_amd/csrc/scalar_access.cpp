@@ -74,6 +74,110 @@ int simdsearchwithlengthFOR(uint32_t initvalue, const __m128i *in, uint32_t bit,
   return lo;
 }
 
+// ---- single-block access to differentially coded blocks ----------------------
+// One block in host memory, one answer: like the FOR accessors above these have no
+// batch dimension (the batched forms are simdcomp_hip_select / _search / _scand1).
+namespace {
+
+// the field at `slot`, not yet summed
+inline uint32_t field_at(const uint32_t *w, uint32_t bit, int slot) {
+  const Field f = locate((size_t)slot, bit);
+  uint32_t v = w[f.word] >> f.shift;
+  if (f.split) v |= w[f.word + 4] << (32 - f.shift);
+  return v & low_ones(bit);
+}
+
+// value number `slot` of the block: the offset plus the fields 0..slot (raw for 32 bits, the offset for 0 bits)
+inline uint32_t d1_value(uint32_t init, const uint32_t *w, uint32_t bit, int slot) {
+  if (bit == 0) return init;
+  if (bit == 32) return w[slot];
+  uint32_t v = init;
+  for (int i = 0; i <= slot; ++i) v += field_at(w, bit, i);
+  return v;
+}
+
+// src/simdpackedsearch.c:29
+inline int bisect_raw(const uint32_t *a, uint32_t key, int imin, int imax) {
+  imax--;
+  while (imin + 1 < imax) {
+    const int imid = imin + (imax - imin) / 2;
+    if (a[imid] >= key) imax = imid;
+    else imin = imid;
+  }
+  return a[imin] >= key ? imin : imax;
+}
+
+}  // namespace
+
+// src/simdpackedselect.c:8096
+uint32_t simdselectd1(uint32_t initvalue, const __m128i *in, uint32_t bit, int slot) {
+  if (bit > 32) return (uint32_t)-1;
+  return d1_value(initvalue, reinterpret_cast<const uint32_t *>(in), bit, slot & 127);
+}
+
+// src/simdpackedsearch.c:8284: first of the first `length` values that is >= key
+int simdsearchwithlengthd1(uint32_t initvalue, const __m128i *in, uint32_t bit, int length, uint32_t key,
+                           uint32_t *presult) {
+  const uint32_t *w = reinterpret_cast<const uint32_t *>(in);
+  if (bit > 32) return -1;
+  if (bit == 32) {
+    if (length > 0) {
+      const int at = bisect_raw(w, key, 0, length);
+      if (w[at] >= key) {
+        *presult = w[at];
+        return at;
+      }
+    }
+  } else if (bit == 0) {
+    if (length > 0 && initvalue >= key) {
+      *presult = initvalue;
+      return 0;
+    }
+  } else {
+    uint32_t v = initvalue;
+    for (int i = 0; i < length && i < 128; ++i) {
+      v += field_at(w, bit, i);
+      if (v >= key) {
+        *presult = v;
+        return i;
+      }
+    }
+  }
+  *presult = key + 1;
+  return length;
+}
+
+// src/simdpackedsearch.c:16583: all 128 values; the offset vector ends up holding the group of four the search
+// stopped in (the last group when nothing was found; untouched for 0 bits; the block's last vector for 32 bits,
+// and only when the key was found).  Element 3 of the vector is the offset of the block.
+int simdsearchd1(__m128i *initOffset, const __m128i *in, uint32_t bit, uint32_t key, uint32_t *presult) {
+  const uint32_t *w = reinterpret_cast<const uint32_t *>(in);
+  uint32_t *o = reinterpret_cast<uint32_t *>(initOffset);
+  if (bit > 32) return -1;
+  const uint32_t init = o[3];
+  const int pos = simdsearchwithlengthd1(init, in, bit, 128, key, presult);
+  if (bit == 0) return pos;
+  if (bit == 32) {
+    if (pos < 128)
+      for (int i = 0; i < 4; ++i) o[i] = w[124 + i];
+    return pos;
+  }
+  const int g = pos < 128 ? pos / 4 : 31;
+  uint32_t v = d1_value(init, w, bit, 4 * g);
+  o[0] = v;
+  for (int i = 1; i < 4; ++i) o[i] = (v += field_at(w, bit, 4 * g + i));
+  return pos;
+}
+
+// src/simdpackedselect.c:15216
+void simdscand1(__m128i *initOffset, const __m128i *in, uint32_t bit) {
+  const uint32_t *w = reinterpret_cast<const uint32_t *>(in);
+  uint32_t *o = reinterpret_cast<uint32_t *>(initOffset);
+  if (bit == 0 || bit > 32) return;
+  const uint32_t init = o[3];
+  for (int i = 0; i < 4; ++i) o[i] = d1_value(init, w, bit, 124 + i);
+}
+
 // src/simdbitpacking.c:14338: the b-bit window is cleared, then the raw value is
 // ORed in (not masked, as in the reference); a split field replaces the low
 // shift+b-32 bits of the lane's next word.
@@ -91,6 +195,17 @@ void simdfastset(__m128i *in128, uint32_t b, uint32_t value, size_t index) {
 // src/simdfor.c:15197
 void simdfastsetFOR(uint32_t initvalue, __m128i *in, uint32_t bit, uint32_t value, size_t index) {
   simdfastset(in, bit, value - initvalue, index);
+}
+
+// src/simdintegratedbitpacking.c:25339
+void simdfastsetd1fromprevious(__m128i *in, uint32_t bit, uint32_t previousvalue, uint32_t value, size_t index) {
+  simdfastset(in, bit, value - previousvalue, index);
+}
+
+// src/simdintegratedbitpacking.c:25347
+void simdfastsetd1(uint32_t initvalue, __m128i *in, uint32_t bit, uint32_t value, size_t index) {
+  const uint32_t prev = index == 0 ? initvalue : simdselectd1(initvalue, in, bit, (int)index - 1);
+  simdfastset(in, bit, value - prev, index);
 }
 
 }  // extern "C"

@@ -110,3 +110,52 @@ def test_single_value_accessors(orc, bit):
         lib.simdfastsetFOR(base, mine.ctypes.data, bit, int(newv[idx]) + base, idx)
         want = orc.simdfastsetFOR(base, want, bit, int(newv[idx]) + base, idx)
         assert np.array_equal(mine[: 16 * bit], want)
+
+
+def test_d1_single_block_accessors_golden(orc):
+    """simdselectd1 / simdsearchwithlengthd1 / simdsearchd1 / simdscand1 of the library (host routines) against the
+    answers the reference gave."""
+    import golden_util as G
+    import oracle
+
+    lib = binding.lib()
+    g = G.load("queries.npz")
+    res = C.c_uint32()
+    for bit in range(33):
+        for kind in range(2):
+            x, init = G.query_block(bit, kind)
+            comp = oracle.aligned_copy(np.concatenate([orc.simdpackwithoutmaskd1(init, x, bit), np.zeros(528, np.uint8)])[:528])
+            keys = G.query_keys(orc.simdunpackd1(init, comp[:16 * bit], bit), bit, kind)
+            for i, slot in enumerate(G.QUERY_SLOTS):
+                assert lib.simdselectd1(init, comp.ctypes.data, bit, slot) == g["select"][bit, kind, 0, i]
+            for ki, key in enumerate(keys):
+                for li, length in enumerate(G.QUERY_LENGTHS):
+                    pos = lib.simdsearchwithlengthd1(init, comp.ctypes.data, bit, length, int(key), C.byref(res))
+                    assert [pos, res.value] == g["search"][bit, kind, 0, ki, li].tolist()
+                o4 = oracle.aligned_copy(np.full(4, init, np.uint32))
+                pos = lib.simdsearchd1(o4.ctypes.data, comp.ctypes.data, bit, int(key), C.byref(res))
+                assert [pos, res.value] + [int(v) for v in o4] == g["searchd1"][bit, kind, ki].tolist()
+            o4 = oracle.aligned_copy(np.full(4, init, np.uint32))
+            lib.simdscand1(o4.ctypes.data, comp.ctypes.data, bit)
+            assert np.array_equal(o4, g["scan"][bit, kind])
+
+
+@pytest.mark.parametrize("bit", [1, 4, 9, 17, 31, 32])
+def test_fastsetd1(orc, ref, bit):
+    """simdfastsetd1 / simdfastsetd1fromprevious rewrite one field exactly as the reference does."""
+    import oracle
+
+    lib = binding.lib()
+    x = synth.sorted_gaps(5 + bit, 128, min(bit, 20), first=100)
+    init = 100
+    base = np.concatenate([orc.simdpackwithoutmaskd1(init, x, bit), np.zeros(528, np.uint8)])[:528]
+    for idx in (0, 1, 63, 127):
+        newv = int(x[idx]) + 1
+        mine, theirs = oracle.aligned_copy(base), oracle.aligned_copy(base)
+        lib.simdfastsetd1(init, mine.ctypes.data, bit, newv, idx)
+        ref.lib.simdfastsetd1(C.c_uint32(init), C.c_void_p(theirs.ctypes.data), C.c_uint32(bit), C.c_uint32(newv), C.c_size_t(idx))
+        assert np.array_equal(mine, theirs)
+        prev = int(x[idx - 1]) if idx else init
+        mine = oracle.aligned_copy(base)
+        lib.simdfastsetd1fromprevious(mine.ctypes.data, bit, prev, newv, idx)
+        assert np.array_equal(mine, theirs)
