@@ -146,10 +146,40 @@ def cpu_baseline(log2n=26, reps=3):
         t1 += orc.time_blocks(0, fn, seeds, payload, out, b, nblk, 1, reps)
         tn += orc.time_blocks(0, fn, seeds, payload, out, b, nblk, ncores, reps)
     total = n * len(WIDTHS)
-    return {"value": total / t1, "unit": "int32/s", "cores": 1, "kind": kind,
+    callers = cpu_callers(orc, lib if kind == "reference" else orc)
+    return {"value": total / t1, "unit": "int32/s", "cores": 1, "kind": kind, "callers": callers,
             "sample": f"simdunpackd1 over 2^{log2n} ints (out of cache) at each b=1..32, best of {reps}, "
                       f"{'oracle/_ref built -O3 -msse4.1' if kind == 'reference' else 'scalar restatement'}",
             "all_cores": {"value": total / tn, "cores": ncores}}
+
+
+def cpu_callers(orc, codec, log2n=24):
+    """The callers either side of the block codec on one host core, same bounded-sample idea: the decode loop of
+    example.c:101-110 over a [width byte][payload] stream, and simdsearchwithlengthd1 once per (random block, key)."""
+    from simdcomp_amd import synth
+
+    nblk = (1 << log2n) // 128
+    widths = synth.skewed_widths(11, nblk, 1, 20)
+    gaps = synth.rand_u32(12, nblk * 128).reshape(nblk, 128)
+    gaps &= ((np.uint64(1) << widths.astype(np.uint64)) - np.uint64(1)).astype(np.uint32)[:, None]
+    ids = (np.cumsum(gaps.reshape(-1).astype(np.uint64)) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    stream = orc.stream_compress(ids, d1=True, codec=codec)
+    best = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        dec = orc.stream_decode(stream, nblk, d1=True, codec=codec)
+        best = min(best, time.perf_counter() - t0)
+    ok = bool(np.array_equal(dec, ids))
+    n, bits, off, status = orc.stream_walk(stream, nblk)
+    seeds = np.concatenate([[0], ids[127::128][:-1]]).astype(np.uint32)
+    nq = 1 << 20
+    qb = (synth.rand_u32(13, nq) % np.uint32(nblk)).astype(np.uint64)
+    keys = (ids.reshape(nblk, 128)[qb.astype(np.int64), synth.rand_u32(14, nq) % np.uint32(128)] + np.uint32(1)).astype(np.uint32)
+    pay = np.concatenate([stream, np.zeros(512, np.uint8)])
+    ts, pos, val = orc.time_search(seeds, pay, off + np.arange(nblk, dtype=np.uint64) + np.uint64(1), bits, qb, keys, codec=codec)
+    return {"stream_decode_int32/s": nblk * 128 / best, "stream_decode_ok": ok and status == 0 and n == nblk,
+            "search_queries/s": nq / ts, "cores": 1,
+            "sample": f"2^{log2n} docIDs, widths 1..20; 2^20 searches with a random block each"}
 
 
 def host_to_host(dev, log2n=28, widths=(1, 8, 16, 32)):

@@ -69,7 +69,7 @@ def mixed(n, nblk, ints, out, reps):
 
 def stream(n, nblk, reps):
     """The example.c byte stream on the device (widths 0..20 skewed small, 2 % of the blocks 32-bit):
-    build, record index, unbuild, chained offsets; next to the CPU decode loop of example.c:101-110."""
+    build, record index, unbuild, chained offsets (the CPU loop of example.c:101-110 is timed by bench.py)."""
     import numpy as np
 
     dev = torch.device("cuda:0")
@@ -124,32 +124,12 @@ def stream(n, nblk, reps):
     whole = sum(res[k]["ms"] for k in ("maxbitsd1", "payload_offsets", "pack_stream")) * 1e-3
     res["compress_to_stream"] = {"ms": round(whole * 1e3, 4), "Gint/s": round(n / whole / 1e9, 1),
                                  "what": "maxbitsd1 + payload_offsets + pack_stream (example.c:56-75)"}
-    try:
-        import oracle
-
-        orc = oracle.Oracle()
-        ref = oracle.Reference() if oracle.have_ref() else orc
-        m = min(nblk, 1 << 19)  # 2^26 integers
-        cut = int(off[m].item()) + m if m < nblk else T + nblk
-        h = strm[:cut].cpu().numpy()
-        best = 1e9
-        import time
-
-        for _ in range(3):
-            t0 = time.perf_counter()
-            dec = orc.stream_decode(h, m, d1=True, codec=ref)
-            best = min(best, time.perf_counter() - t0)
-        assert np.array_equal(dec.view(np.int32), ids[: m * 128].cpu().numpy())
-        res["cpu_stream_decode"] = {"Gint/s": round(m * 128 / best / 1e9, 2), "cores": 1, "ints": m * 128,
-                                    "kind": "reference" if oracle.have_ref() else "port"}
-    except Exception as e:  # pragma: no cover
-        res["cpu_stream_decode"] = str(e)
     print("stream", json.dumps(res), flush=True)
 
 
 def query(n, nblk, reps):
-    """Batched search / select over a mixed-width d1 corpus: random block per query and one query per block,
-    next to the reference's simdsearchwithlengthd1 called per query on one core."""
+    """Batched search / select over a mixed-width d1 corpus: random block per query and one query per block
+    (the reference's per-query search on one core is timed by bench.py)."""
     import numpy as np
 
     dev = torch.device("cuda:0")
@@ -176,22 +156,6 @@ def query(n, nblk, reps):
         res["search_" + name] = {"queries": nq, "ms": round(t * 1e3, 4), "Gquery/s": round(nq / t / 1e9, 2), "GB/s": round(by / t / 1e9, 1)}
         t = timeit(lambda: codec.select(1, arena, slots, bits=bits, offsets=off, initvalues=seeds, query_blocks=qb), reps)
         res["select_" + name] = {"queries": nq, "ms": round(t * 1e3, 4), "Gquery/s": round(nq / t / 1e9, 2)}
-        if qb is not None:
-            try:
-                import oracle
-
-                orc = oracle.Oracle()
-                ref = oracle.Reference() if oracle.have_ref() else orc
-                m = 1 << 20
-                h_pay = np.concatenate([arena.cpu().numpy(), np.zeros(512, np.uint8)])
-                tt, hp, hv = orc.time_search(seeds.cpu().numpy().view(np.uint32), h_pay, off.cpu().numpy().view(np.uint64),
-                                             bits.cpu().numpy(), qb[:m].cpu().numpy().view(np.uint64),
-                                             keys[:m].cpu().numpy().view(np.uint32), codec=ref)
-                assert np.array_equal(hp, pos[:m].cpu().numpy()) and np.array_equal(hv, val[:m].cpu().numpy().view(np.uint32))
-                res["cpu_search_random_blocks"] = {"queries": m, "Mquery/s": round(m / tt / 1e6, 2), "cores": 1,
-                                                   "kind": "reference" if oracle.have_ref() else "port"}
-            except Exception as e:  # pragma: no cover
-                res["cpu_search_random_blocks"] = str(e)
     print("query", json.dumps(res), flush=True)
 
 
