@@ -84,6 +84,35 @@ void simdfastsetFOR(uint32_t initvalue, __m128i *in, uint32_t bit, uint32_t valu
 int simdsearchwithlengthFOR(uint32_t initvalue, const __m128i *in, uint32_t bit, int length, uint32_t key,
                             uint32_t *presult);                                               /* :65 */
 
+/* ---- include/avxbitpacking.h, include/avx512bitpacking.h ---------------------------
+ * 256- / 512-integer blocks with 8 / 16 interleaved lanes (data packed by the reference's AVX paths).  The vector
+ * types exist only when the including program is compiled for those ISAs, as in the reference's headers; other
+ * programs see the same functions with untyped pointers. */
+#if defined(__AVX2__) && !defined(SIMDCOMP_HIP_BUILDING)
+#include <immintrin.h>
+uint32_t avxmaxbits(const uint32_t *begin);                                    /* avxbitpacking.h:22 */
+void avxpack(const uint32_t *in, __m256i *out, const uint32_t bit);            /* :25 */
+void avxpackwithoutmask(const uint32_t *in, __m256i *out, const uint32_t bit); /* :28 */
+void avxunpack(const __m256i *in, uint32_t *out, const uint32_t bit);          /* :31 */
+#else
+uint32_t avxmaxbits(const uint32_t *begin);
+void avxpack(const uint32_t *in, void *out, const uint32_t bit);
+void avxpackwithoutmask(const uint32_t *in, void *out, const uint32_t bit);
+void avxunpack(const void *in, uint32_t *out, const uint32_t bit);
+#endif
+#if defined(__AVX512F__) && !defined(SIMDCOMP_HIP_BUILDING)
+#include <immintrin.h>
+uint32_t avx512maxbits(const uint32_t *begin);                                       /* avx512bitpacking.h */
+void avx512pack(const uint32_t *in, __m512i *out, const uint32_t bit);
+void avx512packwithoutmask(const uint32_t *in, __m512i *out, const uint32_t bit);
+void avx512unpack(const __m512i *in, uint32_t *out, const uint32_t bit);
+#else
+uint32_t avx512maxbits(const uint32_t *begin);
+void avx512pack(const uint32_t *in, void *out, const uint32_t bit);
+void avx512packwithoutmask(const uint32_t *in, void *out, const uint32_t bit);
+void avx512unpack(const void *in, uint32_t *out, const uint32_t bit);
+#endif
+
 #ifdef __cplusplus
 }
 #endif

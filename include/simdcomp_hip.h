@@ -230,6 +230,22 @@ int simdcomp_hip_scand1(uint32_t initvalue, const uint32_t *d_initvalues, const 
                         const uint64_t *d_payload_offsets, const uint8_t *d_bits, uint32_t bit, int stream_layout,
                         size_t nblocks, uint32_t *d_last4_out, void *stream);
 
+/* ---- the 8-lane (AVX2) and 16-lane (AVX-512) wire formats --------------------- */
+
+/* Blocks of 32*lanes integers packed with `lanes` interleaved lanes: value i in
+ * lane i % lanes, row i / lanes, a block is `bit` vectors of 4*lanes bytes --
+ * what avxpack / avxpackwithoutmask / avxunpack (src/avxbitpacking.c:9906-9918,
+ * lanes = 8, 256 integers) and avx512pack / avx512packwithoutmask / avx512unpack
+ * (src/avx512bitpacking.c, lanes = 16, 512 integers) read and write, for
+ * interoperability with data packed by those paths.  lanes = 4 is
+ * simdcomp_hip_pack / _unpack.  nblocks counts blocks of 32*lanes integers;
+ * plain coding at one uniform width only, as in the reference. */
+int simdcomp_hip_pack_lanes(int lanes, const uint32_t *d_in, void *d_out, size_t nblocks, uint32_t bit, int masked,
+                            void *stream);
+int simdcomp_hip_unpack_lanes(int lanes, const void *d_in, uint32_t *d_out, size_t nblocks, uint32_t bit, void *stream);
+/* avxmaxbits / avx512maxbits (src/avxbitpacking.c:17): width of the OR of the 32*lanes integers of each block. */
+int simdcomp_hip_maxbits_lanes(int lanes, const uint32_t *d_in, size_t nblocks, uint8_t *d_bits, void *stream);
+
 /* ---- block-range partitioner and verification reduction -------------------- */
 
 /* Contiguous block range of shard `part` out of `nparts`: blocks are

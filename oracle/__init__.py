@@ -399,6 +399,22 @@ class Oracle(BlockCodec):
         n = self.lib.stream_walk(_ptr(stream), stream.size, max_blocks, _ptr(bits), _ptr(off), C.byref(status))
         return int(n), bits, off, status.value
 
+    # -- 8- / 16-lane wire formats (one block of 32*lanes integers) ------------------------------------
+    def lanes_maxbits(self, lanes, x):
+        self.lib.orc_lanes_maxbits.restype = u32
+        return int(self.lib.orc_lanes_maxbits(u32(lanes), _ptr(x)))
+
+    def lanes_pack(self, lanes, x, bit, masked=False):
+        o = np.zeros(4 * lanes * min(bit, 32), np.uint8)
+        self.lib.orc_lanes_pack(u32(lanes), C.c_int(int(masked)), _ptr(x), _ptr(o), u32(bit))
+        return o
+
+    def lanes_unpack(self, lanes, comp, bit):
+        c = np.concatenate([np.asarray(comp, np.uint8), np.zeros(64, np.uint8)])
+        o = np.zeros(32 * lanes, np.uint32)
+        self.lib.orc_lanes_unpack(u32(lanes), _ptr(c), _ptr(o), u32(bit))
+        return o
+
     def time_search(self, seeds, payload, off, bits, query_blocks, keys, reps=3, codec=None):
         """One simdsearchwithlengthd1 call per query on one core -> (seconds, positions, values)."""
         codec = codec or self
@@ -415,6 +431,52 @@ class Oracle(BlockCodec):
         addr = C.cast(fn_ptr, vp)
         return float(self.lib.cpu_driver_time(kind, addr, _ptr(seeds), _ptr(payload), _ptr(ints), bit, nblocks,
                                               nthreads, reps))
+
+
+REF_AVX_SO = os.path.join(_HERE, "_ref", "libsimdcomp_ref_avx.so")
+
+
+def have_ref_avx():
+    """The reference's AVX2 / AVX-512 packers can run here: the file exists and the CPU has both ISAs."""
+    if not os.path.exists(REF_AVX_SO):
+        return False
+    try:
+        flags = open("/proc/cpuinfo").read()
+    except OSError:
+        return False
+    return " avx2" in flags and " avx512f" in flags
+
+
+class ReferenceAvx:
+    """avxpack / avx512pack families of the compiled reference (src/avxbitpacking.c, src/avx512bitpacking.c)."""
+
+    def __init__(self):
+        self.lib = C.CDLL(REF_AVX_SO)
+        self.f = {}
+        for lanes, pre in ((8, "avx"), (16, "avx512")):
+            mb = getattr(self.lib, pre + "maxbits")
+            mb.restype, mb.argtypes = u32, [vp]
+            fs = [mb]
+            for name in ("pack", "packwithoutmask", "unpack"):
+                g = getattr(self.lib, pre + name)
+                g.restype, g.argtypes = None, [vp, vp, u32]
+                fs.append(g)
+            self.f[lanes] = fs
+
+    def lanes_maxbits(self, lanes, x):
+        return int(self.f[lanes][0](_ptr(x)))
+
+    def lanes_pack(self, lanes, x, bit, masked=False):
+        o = aligned_empty(4 * lanes * bit + 64, np.uint8)
+        o[:] = 0
+        self.f[lanes][1 if masked else 2](_ptr(x), _ptr(o), bit)
+        return o[:4 * lanes * bit].copy()
+
+    def lanes_unpack(self, lanes, comp, bit):
+        c = aligned_copy(np.concatenate([np.asarray(comp, np.uint8), np.zeros(64, np.uint8)]))
+        o = np.zeros(32 * lanes, np.uint32)
+        self.f[lanes][3](_ptr(c), _ptr(o), bit)
+        return o
 
 
 def have_ref():

@@ -160,6 +160,51 @@ void orc_simdunpack(const void *in, uint32_t *out, uint32_t bit) {
   block_unpack_raw((const uint32_t *)in, out, bit);
 }
 
+/* The 8-lane and 16-lane wire formats of src/avxbitpacking.c:9906-9918
+ * (avxpack / avxpackwithoutmask / avxunpack, 256 integers, AVX2) and
+ * src/avx512bitpacking.c (avx512pack / ..., 512 integers): the same rule with
+ * `lanes` interleaved lanes -- value i in lane i % lanes, row i / lanes, word w
+ * of lane l at uint32 index lanes*w + l; a block is 32*lanes integers and
+ * `bit` vectors of 4*lanes bytes.  lanes = 4 is the SSE format above. */
+void orc_lanes_pack(uint32_t lanes, int masked, const uint32_t *in, void *outv, uint32_t bit) {
+  uint32_t *out = (uint32_t *)outv;
+  uint32_t i, n = 32 * lanes, m = masked ? field_mask(bit) : 0xFFFFFFFFu;
+  if (bit == 0 || bit > 32) return;
+  if (bit == 32) {
+    memcpy(out, in, n * sizeof(uint32_t));
+    return;
+  }
+  memset(out, 0, 4u * lanes * bit);
+  for (i = 0; i < n; ++i) {
+    uint32_t lane = i % lanes, p = (i / lanes) * bit, w = p >> 5, s = p & 31u, v = in[i] & m;
+    out[lanes * w + lane] |= v << s;
+    if (s + bit > 32) out[lanes * (w + 1) + lane] |= v >> (32 - s);
+  }
+}
+
+void orc_lanes_unpack(uint32_t lanes, const void *inv, uint32_t *v, uint32_t bit) {
+  const uint32_t *in = (const uint32_t *)inv;
+  uint32_t i, n = 32 * lanes, m = field_mask(bit);
+  if (bit > 32) return;
+  if (bit == 0) {
+    memset(v, 0, n * sizeof(uint32_t));
+    return;
+  }
+  if (bit == 32) {
+    memcpy(v, in, n * sizeof(uint32_t));
+    return;
+  }
+  for (i = 0; i < n; ++i) {
+    uint32_t lane = i % lanes, p = (i / lanes) * bit, w = p >> 5, s = p & 31u;
+    uint32_t f = in[lanes * w + lane] >> s;
+    if (s + bit > 32) f |= in[lanes * (w + 1) + lane] << (32 - s);
+    v[i] = f & m;
+  }
+}
+
+/* avxmaxbits (src/avxbitpacking.c:17) / avx512maxbits */
+uint32_t orc_lanes_maxbits(uint32_t lanes, const uint32_t *in) { return orc_maxbits_length(in, 32 * lanes); }
+
 /* src/simdintegratedbitpacking.c:25058 simdpackwithoutmaskd1(): successive
  * differences seeded by initvalue (Delta, :6-12), packed unmasked.  b == 32
  * stores the raw values and ignores initvalue (:15978-15985). */

@@ -43,6 +43,9 @@ DEVICE_API = {
     "simdcomp_hip_select": (C.c_int, [C.c_int, u32, vp, vp, vp, vp, u32, C.c_int, vp, vp, sz, vp, vp]),
     "simdcomp_hip_search": (C.c_int, [C.c_int, u32, vp, vp, vp, vp, u32, C.c_int, vp, vp, vp, sz, vp, vp, vp, vp]),
     "simdcomp_hip_scand1": (C.c_int, [u32, vp, vp, vp, vp, u32, C.c_int, sz, vp, vp]),
+    "simdcomp_hip_pack_lanes": (C.c_int, [C.c_int, vp, vp, sz, u32, C.c_int, vp]),
+    "simdcomp_hip_unpack_lanes": (C.c_int, [C.c_int, vp, vp, sz, u32, vp]),
+    "simdcomp_hip_maxbits_lanes": (C.c_int, [C.c_int, vp, sz, vp, vp]),
     "simdcomp_hip_compressedbytes": (sz, [sz, u32]),
     "simdcomp_hip_pack_length": (C.c_int, [vp, sz, vp, u32, vp]),
     "simdcomp_hip_unpack_length": (C.c_int, [vp, sz, vp, u32, vp]),
@@ -80,6 +83,14 @@ HOST_API = {
     "simdpackFOR_compressedbytes": (C.c_int, [C.c_int, u32]),
     "simdpackFOR_length": (vp, [u32, vp, C.c_int, vp, u32]),
     "simdunpackFOR_length": (vp, [u32, vp, C.c_int, vp, u32]),
+    "avxmaxbits": (u32, [vp]),
+    "avxpack": (None, [vp, vp, u32]),
+    "avxpackwithoutmask": (None, [vp, vp, u32]),
+    "avxunpack": (None, [vp, vp, u32]),
+    "avx512maxbits": (u32, [vp]),
+    "avx512pack": (None, [vp, vp, u32]),
+    "avx512packwithoutmask": (None, [vp, vp, u32]),
+    "avx512unpack": (None, [vp, vp, u32]),
     "simdselectd1": (u32, [u32, vp, u32, C.c_int]),
     "simdsearchwithlengthd1": (C.c_int, [u32, vp, u32, C.c_int, u32, vp]),
     "simdsearchd1": (C.c_int, [vp, vp, u32, u32, vp]),

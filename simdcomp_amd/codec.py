@@ -240,6 +240,31 @@ def scand1(payload, nblocks, bit=0, bits=None, offsets=None, initvalues=None, in
     return out
 
 
+def pack_lanes(lanes, x, bit, masked=False, out=None):
+    """nblocks x avxpack / avxpackwithoutmask (lanes=8) or avx512pack* (lanes=16)."""
+    x = _i32(x)
+    nblocks = x.numel() // (32 * lanes)
+    if out is None:
+        out = torch.empty(nblocks * 4 * lanes * bit, dtype=torch.uint8, device=x.device)
+    B.check(B.lib().simdcomp_hip_pack_lanes(lanes, B.ptr(x), B.ptr(out), nblocks, bit, int(masked), _stream()), "pack_lanes")
+    return out
+
+
+def unpack_lanes(lanes, payload, nblocks, bit, out=None):
+    if out is None:
+        out = torch.empty(nblocks * 32 * lanes, dtype=torch.int32, device=payload.device)
+    B.check(B.lib().simdcomp_hip_unpack_lanes(lanes, B.ptr(payload), B.ptr(out), nblocks, bit, _stream()), "unpack_lanes")
+    return out
+
+
+def maxbits_lanes(lanes, x):
+    x = _i32(x)
+    nblocks = x.numel() // (32 * lanes)
+    out = torch.empty(nblocks, dtype=torch.uint8, device=x.device)
+    B.check(B.lib().simdcomp_hip_maxbits_lanes(lanes, B.ptr(x), nblocks, B.ptr(out), _stream()), "maxbits_lanes")
+    return out
+
+
 def pack_length(x, bit, out=None):
     x = _i32(x)
     n = x.numel()

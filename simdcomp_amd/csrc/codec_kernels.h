@@ -23,6 +23,11 @@ struct UnpackArgs {
   // the byte stream of example.c:56-75 (a width byte in front of every payload) decoded in place.
   uint32_t stream_layout;
   size_t block_base;       // stream layout: record number of this call's block 0
+  // Wide layouts (uniform width, plain mode, flex kernels only): an AVX2 / AVX-512 block (avxbitpacking.c:9906,
+  // avx512bitpacking.c) is lane_groups = 2 / 4 interleaved 4-lane blocks -- group g holds lanes 4g..4g+3, its row k
+  // is the 4 integers at 4*lane_groups*k + 4g of the wide block and its vector w the 16 bytes at
+  // 16*lane_groups*w + 16g of the wide payload.  nblocks counts the 4-lane blocks.  0 or 1: the plain layout.
+  uint32_t lane_groups;
 };
 
 struct PackArgs {
@@ -42,9 +47,11 @@ struct PackArgs {
   // Per-block widths only: write the byte stream of example.c:56-75 directly -- block k's width byte at
   // payload + off[k] + (chain_base + k), its payload right behind it, any alignment.
   uint32_t stream_layout;
+  uint32_t lane_groups;    // as in UnpackArgs
 };
 
 struct ReduceArgs {
+  uint32_t group;          // RED_MAXBITS: a block is `group` x 128 consecutive integers (0 or 1: 128)
   const uint32_t *in;
   const uint32_t *seeds;
   uint32_t *seeds_out;

@@ -55,6 +55,7 @@ __global__ __launch_bounds__(256) void k_unpack_flex(UnpackArgs a) {
   const int h = lane >> 5, k = lane & 31;
   u32x4 *slot = lds[wv][h];
   const uint8_t *payload_bytes = static_cast<const uint8_t *>(a.payload);
+  const size_t S = a.lane_groups > 1 ? a.lane_groups : 1;  // 4-lane groups per wide block (see UnpackArgs)
   const size_t per_iter = (size_t)BLOCKS_PER_STEP * U;
   const size_t ntiles = (a.nblocks + per_iter - 1) / per_iter;
 
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(256) void k_unpack_flex(UnpackArgs a) {
       if (a.off) {
         if (valid[u]) pbase[u] += a.off[blk[u]] + (a.stream_layout ? a.block_base + blk[u] + 1 : 0);
       } else {
-        pbase[u] += blk[u] * 16 * (size_t)b[u];
+        pbase[u] += (blk[u] / S) * (16 * (size_t)b[u] * S) + 16 * (blk[u] % S);
       }
       if constexpr (MODE != MODE_PLAIN) {
         seed[u] = a.seeds ? (valid[u] ? a.seeds[blk[u]] : 0u) : a.seed0;
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(256) void k_unpack_flex(UnpackArgs a) {
         const size_t nval = start < a.length ? (a.length - start < 128 ? a.length - start : 128) : 0;
         nvec = (uint32_t)((((nval + 3) / 4) * b[u] + 31) / 32);
       }
-      if (valid[u] && (uint32_t)k < nvec) ld[u] = *reinterpret_cast<const u32x4_u *>(pbase[u] + 16 * k);
+      if (valid[u] && (uint32_t)k < nvec) ld[u] = *reinterpret_cast<const u32x4_u *>(pbase[u] + 16 * S * k);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(256) void k_unpack_flex(UnpackArgs a) {
         }
       }
       if (valid[u]) {
-        uint32_t *o = a.out + blk[u] * 128 + 4 * k;
+        uint32_t *o = a.out + (blk[u] / S) * (128 * S) + 4 * S * k + 4 * (blk[u] % S);
         if constexpr (TAIL) {
           const size_t idx = blk[u] * 128 + 4 * (size_t)k;
           if (idx + 4 <= a.length) {
@@ -175,6 +176,7 @@ __global__ __launch_bounds__(256) void k_pack_flex(PackArgs a) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int h = lane >> 5, k = lane & 31;
   uint8_t *payload_bytes = static_cast<uint8_t *>(a.payload);
+  const size_t S = a.lane_groups > 1 ? a.lane_groups : 1;  // 4-lane groups per wide block (see UnpackArgs)
   const size_t per_iter = (size_t)BLOCKS_PER_STEP * U;
   const size_t ntiles = (a.nblocks + per_iter - 1) / per_iter;
 
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(256) void k_pack_flex(PackArgs a) {
       if (a.off) {
         if (valid[u]) pbase[u] += a.off[blk[u]] + (a.stream_layout ? a.chain_base + blk[u] + 1 : 0);
       } else {
-        pbase[u] += blk[u] * 16 * (size_t)b[u];
+        pbase[u] += (blk[u] / S) * (16 * (size_t)b[u] * S) + 16 * (blk[u] % S);
       }
       seed[u] = a.seed0;
       if constexpr (MODE == MODE_D1) {
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(256) void k_pack_flex(PackArgs a) {
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const size_t idx = blk[u] * 128 + 4 * (size_t)k;
+      const size_t idx = (blk[u] / S) * (128 * S) + 4 * S * (size_t)k + 4 * (blk[u] % S);
       x[u] = u32x4{0, 0, 0, 0};
       carry[u] = u32x4{0, 0, 0, 0};
       if constexpr (GENERIC) {
@@ -308,9 +310,9 @@ __global__ __launch_bounds__(256) void k_pack_flex(PackArgs a) {
       }
       if (valid[u]) {
         if (raw) {
-          if (!GENERIC) *reinterpret_cast<u32x4_u *>(pbase[u] + 16 * k) = x[u];
+          if (!GENERIC) *reinterpret_cast<u32x4_u *>(pbase[u] + 16 * S * k) = x[u];
         } else if (last && w < nvec) {
-          *reinterpret_cast<u32x4_u *>(pbase[u] + 16 * w) = acc;
+          *reinterpret_cast<u32x4_u *>(pbase[u] + 16 * S * w) = acc;
         }
         if (!GENERIC && a.off && a.stream_layout && k == 0) pbase[u][-1] = (uint8_t)bu;
         if (MODE == MODE_D1 && a.seeds_out && k == 0) a.seeds_out[blk[u]] = seed[u];
@@ -674,6 +676,9 @@ __global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
       x[u] = u32x4{0, 0, 0, 0};
       seed[u] = a.seed0;
       if (valid[u]) {
+        if (WHAT == RED_MAXBITS && a.group > 1) {
+          for (uint32_t g = 0; g < a.group; ++g) x[u] |= *reinterpret_cast<const u32x4 *>(a.in + (blk * a.group + g) * 128 + 4 * k);
+        } else
         x[u] = *reinterpret_cast<const u32x4 *>(a.in + blk * 128 + 4 * k);
         if constexpr (WHAT == RED_MAXBITSD1) {
           if (a.seeds) seed[u] = a.seeds[blk];
@@ -952,7 +957,7 @@ hipError_t launch_unpack(int mode, bool tail, const UnpackArgs &a, hipStream_t s
   const bool mixed = a.bits != nullptr && a.off != nullptr;
   const bool uniform = a.bits == nullptr && a.off == nullptr;
   const bool seeds_ok = mode == MODE_PLAIN || a.seeds != nullptr;
-  if (tail || !(mixed || uniform) || !seeds_ok) {
+  if (tail || !(mixed || uniform) || !seeds_ok || a.lane_groups > 1) {
     launch_unpack_flex(mode, tail, a, st);
     return hipGetLastError();
   }
@@ -1024,7 +1029,7 @@ hipError_t launch_pack(int mode, bool masked, bool generic, const PackArgs &a, h
   const bool uniform = a.bits == nullptr && a.off == nullptr;
   const bool seeds_ok = mode != MODE_FOR || a.seeds != nullptr;
   if (mode == MODE_FOR) masked = false;
-  if (generic || !(mixed || uniform) || !seeds_ok) {
+  if (generic || !(mixed || uniform) || !seeds_ok || a.lane_groups > 1) {
     launch_pack_flex(mode, masked, generic, a, st);
     return hipGetLastError();
   }

@@ -445,6 +445,50 @@ int simdcomp_hip_scand1(uint32_t initvalue, const uint32_t *d_initvalues, const 
                   stream_layout, a, stream);
 }
 
+namespace {
+int lanes_ok(int lanes) { return lanes == 4 || lanes == 8 || lanes == 16; }
+}  // namespace
+
+int simdcomp_hip_pack_lanes(int lanes, const uint32_t *d_in, void *d_out, size_t nblocks, uint32_t bit, int masked,
+                            void *stream) {
+  if (!lanes_ok(lanes)) return fail(SIMDCOMP_HIP_EMODE, "lanes must be 4, 8 or 16");
+  if (int rc = check_common(d_in, d_out, nblocks, bit, bit != 0)) return rc;
+  sc::PackArgs a{};
+  a.in = d_in;
+  a.payload = d_out;
+  a.lane_groups = (uint32_t)lanes / 4;
+  a.nblocks = nblocks * a.lane_groups;
+  a.length = a.nblocks * 128;
+  a.bit = bit;
+  return hip_result(sc::launch_pack(sc::MODE_PLAIN, masked != 0, false, a, as_stream(stream)), "pack launch");
+}
+
+int simdcomp_hip_unpack_lanes(int lanes, const void *d_in, uint32_t *d_out, size_t nblocks, uint32_t bit, void *stream) {
+  if (!lanes_ok(lanes)) return fail(SIMDCOMP_HIP_EMODE, "lanes must be 4, 8 or 16");
+  if (int rc = check_common(d_out, d_in, nblocks, bit, bit != 0)) return rc;
+  sc::UnpackArgs a{};
+  a.payload = d_in;
+  a.out = d_out;
+  a.lane_groups = (uint32_t)lanes / 4;
+  a.nblocks = nblocks * a.lane_groups;
+  a.length = a.nblocks * 128;
+  a.bit = bit;
+  return hip_result(sc::launch_unpack(sc::MODE_PLAIN, false, a, as_stream(stream)), "unpack launch");
+}
+
+int simdcomp_hip_maxbits_lanes(int lanes, const uint32_t *d_in, size_t nblocks, uint8_t *d_bits, void *stream) {
+  if (!lanes_ok(lanes)) return fail(SIMDCOMP_HIP_EMODE, "lanes must be 4, 8 or 16");
+  if (nblocks == 0) return SIMDCOMP_HIP_OK;
+  if (!d_in || !d_bits) return fail(SIMDCOMP_HIP_ENULL, "NULL pointer");
+  if (!aligned16(d_in)) return fail(SIMDCOMP_HIP_EALIGN, "pointer not 16-byte aligned");
+  sc::ReduceArgs a{};
+  a.group = (uint32_t)lanes / 4;
+  a.in = d_in;
+  a.bits_out = d_bits;
+  a.nblocks = nblocks;
+  return hip_result(sc::launch_reduce(sc::RED_MAXBITS, a, as_stream(stream)), "maxbits launch");
+}
+
 int simdcomp_hip_checksum(const uint32_t *d_data, const uint32_t *d_other, size_t nwords, uint64_t index0,
                           uint64_t *d_acc, void *stream) {
   if (nwords == 0) return SIMDCOMP_HIP_OK;

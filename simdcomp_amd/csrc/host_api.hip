@@ -90,41 +90,44 @@ void d2h(void *dst, const void *src, size_t n, hipStream_t st) {
 
 // ---- one 128-integer block ---------------------------------------------------
 
-void block_pack(int mode, bool masked, uint32_t initvalue, const uint32_t *in, void *out, uint32_t bit) {
+// groups = 1: the 4-lane block of 128 integers; 2 / 4: one 8- / 16-lane block of 256 / 512 integers (plain mode)
+void block_pack(int mode, bool masked, uint32_t initvalue, const uint32_t *in, void *out, uint32_t bit, uint32_t groups = 1) {
   if (bit > 32) return;  // the reference's switch falls through and does nothing
   Staging &s = staging();
   std::lock_guard<std::mutex> lock(s.mu);
-  s.reserve(0, 512, 512);
+  s.reserve(0, 512 * groups, 512 * groups);
   hipStream_t st = s.stream[0];
-  h2d(s.din(0), in, 512, st);
+  h2d(s.din(0), in, 512 * (size_t)groups, st);
   sc::PackArgs a{};
   a.in = reinterpret_cast<const uint32_t *>(s.din(0));
   a.payload = s.dout(0);
-  a.nblocks = 1;
-  a.length = 128;
+  a.nblocks = groups;
+  a.length = 128 * (size_t)groups;
   a.bit = bit;
   a.seed0 = initvalue;  // seeds == nullptr: block 0 of a chained d1 stream / uniform frame base
+  a.lane_groups = groups;
   ck(sc::launch_pack(mode, masked, false, a, st), "pack launch");
-  d2h(out, s.dout(0), 16 * (size_t)bit, st);
+  d2h(out, s.dout(0), 16 * (size_t)bit * groups, st);
   ck(hipStreamSynchronize(st), "hipStreamSynchronize");
 }
 
-void block_unpack(int mode, uint32_t initvalue, const void *in, uint32_t *out, uint32_t bit) {
+void block_unpack(int mode, uint32_t initvalue, const void *in, uint32_t *out, uint32_t bit, uint32_t groups = 1) {
   if (bit > 32) return;
   Staging &s = staging();
   std::lock_guard<std::mutex> lock(s.mu);
-  s.reserve(0, 512, 512);
+  s.reserve(0, 512 * groups, 512 * groups);
   hipStream_t st = s.stream[0];
-  h2d(s.din(0), in, 16 * (size_t)bit, st);
+  h2d(s.din(0), in, 16 * (size_t)bit * groups, st);
   sc::UnpackArgs a{};
   a.payload = s.din(0);
   a.out = reinterpret_cast<uint32_t *>(s.dout(0));
-  a.nblocks = 1;
-  a.length = 128;
+  a.nblocks = groups;
+  a.length = 128 * (size_t)groups;
   a.bit = bit;
   a.seed0 = initvalue;
+  a.lane_groups = groups;
   ck(sc::launch_unpack(mode, false, a, st), "unpack launch");
-  d2h(out, s.dout(0), 512, st);
+  d2h(out, s.dout(0), 512 * (size_t)groups, st);
   ck(hipStreamSynchronize(st), "hipStreamSynchronize");
 }
 
@@ -270,6 +273,18 @@ void simdpackwithoutmask(const uint32_t *in, __m128i *out, const uint32_t bit) {
 void simdunpack(const __m128i *in, uint32_t *out, const uint32_t bit) {
   block_unpack(sc::MODE_PLAIN, 0, in, out, bit);
 }
+
+// ---- the 8- and 16-lane wire formats (include/avxbitpacking.h:22-31, include/avx512bitpacking.h) ----
+// Declared with __m256i / __m512i in simdcomp.h when the including program is built for those ISAs; the library
+// itself only moves bytes, so the definitions take untyped pointers.
+uint32_t avxmaxbits(const uint32_t *begin) { return maxbits_length(begin, 256); }
+void avxpack(const uint32_t *in, void *out, const uint32_t bit) { block_pack(sc::MODE_PLAIN, true, 0, in, out, bit, 2); }
+void avxpackwithoutmask(const uint32_t *in, void *out, const uint32_t bit) { block_pack(sc::MODE_PLAIN, false, 0, in, out, bit, 2); }
+void avxunpack(const void *in, uint32_t *out, const uint32_t bit) { block_unpack(sc::MODE_PLAIN, 0, in, out, bit, 2); }
+uint32_t avx512maxbits(const uint32_t *begin) { return maxbits_length(begin, 512); }
+void avx512pack(const uint32_t *in, void *out, const uint32_t bit) { block_pack(sc::MODE_PLAIN, true, 0, in, out, bit, 4); }
+void avx512packwithoutmask(const uint32_t *in, void *out, const uint32_t bit) { block_pack(sc::MODE_PLAIN, false, 0, in, out, bit, 4); }
+void avx512unpack(const void *in, uint32_t *out, const uint32_t bit) { block_unpack(sc::MODE_PLAIN, 0, in, out, bit, 4); }
 
 __m128i *simdpack_length(const uint32_t *in, size_t length, __m128i *out, const uint32_t bit) {
   return static_cast<__m128i *>(pack_length_host(0, 0, in, length, out, bit));

@@ -1,0 +1,107 @@
+"""The 8-lane (AVX2, src/avxbitpacking.c:9906-9918) and 16-lane (AVX-512,
+src/avx512bitpacking.c) wire formats: restatement against the reference's
+answers (tests/golden/lanes.npz) and, on a CPU that has both ISAs, against the
+compiled reference; the HIP path against both (GPU tests)."""
+import numpy as np
+import pytest
+
+import golden_util as G
+from simdcomp_amd import synth
+
+CASES = ((0, False), (1, True), (1, False))  # (input kind, masked) in the order of the fixture
+
+
+def inputs(lanes, bit):
+    n = 32 * lanes
+    return synth.random_bits(1100 + bit, n, bit), synth.rand_u32(1200 + bit, n)
+
+
+@pytest.mark.parametrize("lanes", [8, 16])
+def test_golden_lanes_restatement(orc, lanes):
+    g = G.load("lanes.npz")
+    for bit in range(33):
+        xs = inputs(lanes, bit)
+        for j, (kind, masked) in enumerate(CASES):
+            c = orc.lanes_pack(lanes, xs[kind], bit, masked)
+            assert np.array_equal(c, g[f"packed{lanes}"][bit, j, :c.size]), (lanes, bit, j)
+            assert np.array_equal(orc.lanes_unpack(lanes, c, bit), g[f"unpacked{lanes}"][bit, j])
+        assert [orc.lanes_maxbits(lanes, xs[0]), orc.lanes_maxbits(lanes, xs[1])] == g[f"maxbits{lanes}"][bit].tolist()
+
+
+@pytest.mark.parametrize("lanes", [8, 16])
+def test_lanes_against_reference(orc, lanes):
+    import oracle
+
+    if not oracle.have_ref_avx():
+        pytest.skip("compiled AVX reference absent or CPU without AVX2 + AVX-512F")
+    ra = oracle.ReferenceAvx()
+    for bit in range(33):
+        for seed in range(3):
+            x = synth.rand_u32(31 * bit + seed, 32 * lanes) >> np.uint32((32 - bit) if (seed == 0 and bit) else 0)
+            for masked in (False, True):
+                c = ra.lanes_pack(lanes, x, bit, masked)
+                assert np.array_equal(c, orc.lanes_pack(lanes, x, bit, masked))
+                assert np.array_equal(ra.lanes_unpack(lanes, c, bit), orc.lanes_unpack(lanes, c, bit))
+            assert ra.lanes_maxbits(lanes, x) == orc.lanes_maxbits(lanes, x)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lanes", [8, 16])
+def test_gpu_lanes(orc, lanes):
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from simdcomp_amd import codec
+
+    def to_dev(a):
+        return torch.from_numpy(np.ascontiguousarray(a).view(np.int32 if a.dtype == np.uint32 else a.dtype)).cuda()
+
+    g = G.load("lanes.npz")
+    n = 32 * lanes
+    for bit in range(33):
+        xs = inputs(lanes, bit)
+        for j, (kind, masked) in enumerate(CASES):
+            got = codec.pack_lanes(lanes, to_dev(xs[kind]), bit, masked=masked).cpu().numpy()
+            assert np.array_equal(got, g[f"packed{lanes}"][bit, j, :got.size]), (lanes, bit, j)
+            dec = codec.unpack_lanes(lanes, to_dev(np.concatenate([got, np.zeros(16, np.uint8)])), 1, bit)
+            assert np.array_equal(dec.cpu().numpy().view(np.uint32), g[f"unpacked{lanes}"][bit, j])
+        # many blocks, ragged count, with canaries; widths from the device reduction
+        nblk = 517
+        x = synth.random_bits(1300 + bit, nblk * n, bit)
+        want = np.concatenate([orc.lanes_pack(lanes, x[k * n:(k + 1) * n], bit) for k in range(nblk)]) if bit else np.zeros(0, np.uint8)
+        buf = torch.full((want.size + 64,), 0xA5, dtype=torch.uint8, device="cuda")
+        codec.pack_lanes(lanes, to_dev(x), bit, out=buf)
+        got = buf.cpu().numpy()
+        assert np.array_equal(got[:want.size], want) and (got[want.size:] == 0xA5).all()
+        out = torch.full((nblk * n + 16,), 0x5A5A5A5A, dtype=torch.int32, device="cuda")
+        codec.unpack_lanes(lanes, buf, nblk, bit, out=out)
+        got = out.cpu().numpy().view(np.uint32)
+        assert np.array_equal(got[:nblk * n], x) and (got[nblk * n:] == 0x5A5A5A5A).all()
+        assert np.array_equal(codec.maxbits_lanes(lanes, to_dev(x)).cpu().numpy(),
+                              np.array([orc.lanes_maxbits(lanes, x[k * n:(k + 1) * n]) for k in range(nblk)], np.uint8))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lanes", [8, 16])
+def test_gpu_lanes_host_api(lanes):
+    """avxpack / avxpackwithoutmask / avxunpack / avxmaxbits (and the avx512 family) of the library, host pointers."""
+    import ctypes as C
+
+    from simdcomp_amd import binding
+
+    lib = binding.lib()
+    pre = "avx" if lanes == 8 else "avx512"
+    g = G.load("lanes.npz")
+    n = 32 * lanes
+    for bit in range(33):
+        xs = inputs(lanes, bit)
+        for j, (kind, masked) in enumerate(CASES):
+            x = np.ascontiguousarray(xs[kind])
+            out = np.full(4 * lanes * bit + 32, 0xA5, np.uint8)
+            getattr(lib, pre + ("pack" if masked else "packwithoutmask"))(x.ctypes.data, out.ctypes.data, bit)
+            assert np.array_equal(out[:4 * lanes * bit], g[f"packed{lanes}"][bit, j, :4 * lanes * bit]), (lanes, bit, j)
+            assert (out[4 * lanes * bit:] == 0xA5).all()
+            dec = np.zeros(n, np.uint32)
+            getattr(lib, pre + "unpack")(out.ctypes.data, dec.ctypes.data, bit)
+            assert np.array_equal(dec, g[f"unpacked{lanes}"][bit, j])
+        assert [getattr(lib, pre + "maxbits")(np.ascontiguousarray(x).ctypes.data) for x in xs] == g[f"maxbits{lanes}"][bit].tolist()

@@ -25,6 +25,8 @@ Files written
   queries.npz   simdselectd1 / simdsearchwithlengthd1 / simdsearchd1 / simdscand1
                 and simdselectFOR / simdsearchwithlengthFOR answers of the
                 reference on sorted and unsorted blocks of every width
+  lanes.npz     avxpack / avx512pack families (8- and 16-lane wire formats) on
+                one block per width (needs a CPU with AVX2 and AVX-512F)
 """
 import os
 import sys
@@ -209,6 +211,27 @@ def gen_queries(ref):
     np.savez_compressed(os.path.join(OUT, "queries.npz"), select=sel, search=srch, searchd1=full, scan=scan)
 
 
+def gen_lanes():
+    """avxpack / avxpackwithoutmask / avxunpack / avxmaxbits and the avx512 family of the reference on one block
+    per width: in-range input through the unmasked packer, arbitrary 32-bit input through both."""
+    ra = oracle.ReferenceAvx()
+    out = {}
+    for lanes in (8, 16):
+        n = 32 * lanes
+        packed = np.zeros((33, 3, 4 * lanes * 32), np.uint8)   # [bit][in-range unmasked, wild masked, wild unmasked]
+        unpacked = np.zeros((33, 3, n), np.uint32)
+        mb = np.zeros((33, 2), np.uint32)
+        for bit in range(33):
+            xs = (synth.random_bits(1100 + bit, n, bit), synth.rand_u32(1200 + bit, n))
+            for j, (x, masked) in enumerate(((xs[0], False), (xs[1], True), (xs[1], False))):
+                c = ra.lanes_pack(lanes, x, bit, masked)
+                packed[bit, j, :c.size] = c
+                unpacked[bit, j] = ra.lanes_unpack(lanes, c, bit)
+            mb[bit] = [ra.lanes_maxbits(lanes, xs[0]), ra.lanes_maxbits(lanes, xs[1])]
+        out[f"packed{lanes}"], out[f"unpacked{lanes}"], out[f"maxbits{lanes}"] = packed, unpacked, mb
+    np.savez_compressed(os.path.join(OUT, "lanes.npz"), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     ORC = oracle.Oracle()  # used only for its FNV helper
@@ -218,5 +241,7 @@ if __name__ == "__main__":
     gen_corpus(REF)
     gen_stream(REF)
     gen_queries(REF)
+    if oracle.have_ref_avx():
+        gen_lanes()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

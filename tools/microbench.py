@@ -203,6 +203,12 @@ def main():
                 f = lambda: codec.packFOR(seeds, ints, b, out=payload)
             elif what == "maxbitsd1":
                 f = lambda: codec.maxbitsd1(ints, initvalues=seeds)
+            elif what in ("unpack8", "unpack16"):
+                L = int(what[6:])
+                f = lambda: codec.unpack_lanes(L, payload, n // (32 * L), b, out=out)
+            elif what in ("pack8", "pack16"):
+                L = int(what[4:])
+                f = lambda: codec.pack_lanes(L, ints, b, out=payload)
             else:
                 raise SystemExit(what)
             t = timeit(f, a.reps)
