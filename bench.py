@@ -107,6 +107,25 @@ def encode_leg(corpora, nblocks, seed0, dev, reps=3):
             "timing": f"best of {reps} launches per width, HIP events", "per_width": table}
 
 
+def ceilings(out):
+    """Plain device-memory rates on this GPU for scale (not the roofline's peak): torch's device-to-device copy
+    and fill over the 4 GiB output buffer, best of 5, HIP events."""
+    half = out.numel() // 2
+    res = {}
+    for name, fn, nbytes in (("copy_d2d", lambda: out[:half].copy_(out[half:2 * half]), 8 * half),
+                             ("fill", lambda: out.fill_(7), 4 * out.numel())):
+        best = 1e9
+        for _ in range(6):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            e1.synchronize()
+            best = min(best, e0.elapsed_time(e1) * 1e-3)
+        res[name + "_GB/s"] = round(nbytes / best / 1e9, 1)
+    return res
+
+
 def measured_traffic(nblocks):
     """Average HBM bytes per launch from the committed PMC summary (separate
     rocprofv3 --pmc passes of this same command, tools/summarize_profiles.py);
@@ -234,11 +253,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # under torch.distributed.run (RANK set) the process group is always created, also for one rank, so that the
+    # same code path runs at every N
+    distributed = world > 1 or "RANK" in os.environ
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     # block-range shard of the global corpus (weak scaling: 2^log2n docIDs per GPU)
     total_blocks = world * ((1 << a.log2n) // 128)
@@ -266,7 +289,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -280,7 +303,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if distributed:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(verify, op=dist.ReduceOp.SUM)  # the verification reduction (RCCL)
     elapsed = float(t.item())
@@ -328,6 +351,7 @@ def main():
                          "min_frac": min(v["frac"] for v in table.values()),
                          "per_width": table},
         }
+        line["roofline"]["measured_ceilings"] = ceilings(out)
         if not a.no_encode:
             del out
             line["encode"] = encode_leg(corpora, nblocks, seed0, dev)
@@ -338,7 +362,7 @@ def main():
             torch.cuda.empty_cache()
             line["host_to_host"] = host_to_host(dev)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
 
