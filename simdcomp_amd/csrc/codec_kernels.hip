@@ -615,9 +615,21 @@ __global__ __launch_bounds__(BS) void k_pack_fast(PackArgs a) {
     t.w |= dpp0<CTRL>(t.w) & same;                                                    \
   }
       SC_SEG_STEP(1, DPP_ROW_SHR1)
-      SC_SEG_STEP(2, DPP_ROW_SHR2)
-      SC_SEG_STEP(4, DPP_ROW_SHR4)
-      SC_SEG_STEP(8, DPP_ROW_SHR8)
+      if constexpr (B < 0) {
+        // per-block widths: a word holds at most ceil(32 / b) rows, so the wider both blocks of this wave are, the
+        // fewer doubling steps their segments need (wave-uniform branches; a skipped step would have added nothing)
+        if (__any(bu < 16)) {
+          SC_SEG_STEP(2, DPP_ROW_SHR2)
+          if (__any(bu < 8)) {
+            SC_SEG_STEP(4, DPP_ROW_SHR4)
+            if (__any(bu < 4)) { SC_SEG_STEP(8, DPP_ROW_SHR8) }
+          }
+        }
+      } else {
+        SC_SEG_STEP(2, DPP_ROW_SHR2)
+        SC_SEG_STEP(4, DPP_ROW_SHR4)
+        SC_SEG_STEP(8, DPP_ROW_SHR8)
+      }
 #undef SC_SEG_STEP
       if constexpr (B < 0 || ((15 * B) >> 5) == ((16 * B) >> 5)) {
         const uint32_t same = (k >= 16 && ((15u * bu) >> 5) == w) ? 0xFFFFFFFFu : 0u;
@@ -899,7 +911,10 @@ constexpr int REDUCE_U = 4;
 // very wide blocks prefer 256 threads.  The per-block-width kernels chase two
 // dependent loads (offset, then payload) and measured best with four steps.
 constexpr int unpack_threads(int b) { return (b < 0 || b >= 28) ? 256 : 128; }
-constexpr int unpack_steps(int b) { return b < 0 ? 4 : (b <= 14 ? 2 : 1); }
+#ifndef SC_MIXED_UNPACK_STEPS
+#define SC_MIXED_UNPACK_STEPS 4
+#endif
+constexpr int unpack_steps(int b) { return b < 0 ? SC_MIXED_UNPACK_STEPS : (b <= 14 ? 2 : 1); }
 // Widths 1..7 gain 3-17 points of HBM peak from dedicated prefetch workgroups
 // (one per 16 decode workgroups, 20 MiB of output ahead: the plateau of a
 // sweep over group size 8..512 and distance 4..64 MiB); from 8 bits on the
