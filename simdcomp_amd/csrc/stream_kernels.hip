@@ -27,7 +27,10 @@ namespace sc {
 // one word per block, so a wave takes U blocks per half with all loads issued
 // up front to have enough bytes in flight.  Lanes past a payload's end re-read
 // its last vector; a zero-width block reads the first 16 bytes of `sums`.
-constexpr int SUMS_U = 4;
+#ifndef SC_SUMS_U
+#define SC_SUMS_U 4
+#endif
+constexpr int SUMS_U = SC_SUMS_U;
 
 __global__ __launch_bounds__(256) void k_block_sums(const uint8_t *payload, const uint64_t *off, const uint8_t *bits,
                                                     size_t nblocks, uint32_t stream_layout, uint32_t *sums) {
