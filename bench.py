@@ -165,11 +165,20 @@ def cpu_baseline(log2n=26, reps=3):
         t1 += orc.time_blocks(0, fn, seeds, payload, out, b, nblk, 1, reps)
         tn += orc.time_blocks(0, fn, seeds, payload, out, b, nblk, ncores, reps)
     total = n * len(WIDTHS)
+    avx2 = None
+    if kind == "reference" and oracle.have_ref_avx():
+        # the reference's fastest CPU path for scale: avxunpack (8-lane format, no differential coding)
+        ra = oracle.ReferenceAvx()
+        ta = 0.0
+        for b in WIDTHS:
+            payload = rng.integers(0, 256, nblk * 16 * b, dtype=np.uint8)
+            ta += orc.time_blocks(4 + 1, ra.f[8][3], None, payload, out, b, nblk // 2, 1, reps)
+        avx2 = {"value": total / ta, "unit": "int32/s", "cores": 1, "what": "avxunpack (plain, 256-integer blocks)"}
     callers = cpu_callers(orc, lib if kind == "reference" else orc)
     return {"value": total / t1, "unit": "int32/s", "cores": 1, "kind": kind, "callers": callers,
             "sample": f"simdunpackd1 over 2^{log2n} ints (out of cache) at each b=1..32, best of {reps}, "
                       f"{'oracle/_ref built -O3 -msse4.1' if kind == 'reference' else 'scalar restatement'}",
-            "all_cores": {"value": total / tn, "cores": ncores}}
+            "all_cores": {"value": total / tn, "cores": ncores}, "avx2_comparator": avx2}
 
 
 def cpu_callers(orc, codec, log2n=24):

@@ -20,7 +20,7 @@ typedef void (*pack_seeded_fn)(uint32_t, const uint32_t *, void *, uint32_t);
 typedef void (*pack_plain_fn)(const uint32_t *, void *, uint32_t);
 
 typedef struct {
-  int kind; /* 0 unpack seeded, 1 unpack plain, 2 pack seeded, 3 pack plain */
+  int kind; /* low 2 bits: 0 unpack seeded, 1 unpack plain, 2 pack seeded, 3 pack plain; kind >> 2: block widening */
   void *fn;
   const uint32_t *seeds;
   const uint8_t *payload_c;
@@ -35,21 +35,23 @@ typedef struct {
 static void *run_job(void *arg) {
   job_t *j = (job_t *)arg;
   size_t k;
-  const size_t stride = 16u * j->bit;
+  /* kind >> 2 widens the block: 0 = 128 integers (4 lanes), 1 = 256 (the 8-lane AVX2 format), 2 = 512 (AVX-512) */
+  const size_t ints = (size_t)128 << (j->kind >> 2);
+  const size_t stride = (ints / 8) * j->bit;
   for (k = j->first; k < j->last; ++k) {
     size_t slot = j->ring ? (k % j->ring) : k;
-    switch (j->kind) {
+    switch (j->kind & 3) {
     case 0:
-      ((unpack_seeded_fn)j->fn)(j->seeds[k], j->payload_c + k * stride, j->ints + slot * 128, j->bit);
+      ((unpack_seeded_fn)j->fn)(j->seeds[k], j->payload_c + k * stride, j->ints + slot * ints, j->bit);
       break;
     case 1:
-      ((unpack_plain_fn)j->fn)(j->payload_c + k * stride, j->ints + slot * 128, j->bit);
+      ((unpack_plain_fn)j->fn)(j->payload_c + k * stride, j->ints + slot * ints, j->bit);
       break;
     case 2:
-      ((pack_seeded_fn)j->fn)(j->seeds[k], j->ints_c + slot * 128, j->payload + k * stride, j->bit);
+      ((pack_seeded_fn)j->fn)(j->seeds[k], j->ints_c + slot * ints, j->payload + k * stride, j->bit);
       break;
     default:
-      ((pack_plain_fn)j->fn)(j->ints_c + slot * 128, j->payload + k * stride, j->bit);
+      ((pack_plain_fn)j->fn)(j->ints_c + slot * ints, j->payload + k * stride, j->bit);
       break;
     }
   }
