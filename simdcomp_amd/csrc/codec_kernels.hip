@@ -681,21 +681,25 @@ __global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
     u32x4 x[U];
     uint32_t seed[U];
     bool valid[U];
+    // every load is issued unconditionally (a block past the end re-reads the last one; only the stores are
+    // predicated): behind a branch the loads of the U steps would wait for one another
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const size_t blk = first + 2 * (size_t)u;
       valid[u] = blk < a.nblocks;
-      x[u] = u32x4{0, 0, 0, 0};
+      const size_t bc = valid[u] ? blk : a.nblocks - 1;
       seed[u] = a.seed0;
-      if (valid[u]) {
-        if (WHAT == RED_MAXBITS && a.group > 1) {
-          for (uint32_t g = 0; g < a.group; ++g) x[u] |= *reinterpret_cast<const u32x4 *>(a.in + (blk * a.group + g) * 128 + 4 * k);
-        } else
-        x[u] = *reinterpret_cast<const u32x4 *>(a.in + blk * 128 + 4 * k);
-        if constexpr (WHAT == RED_MAXBITSD1) {
-          if (a.seeds) seed[u] = a.seeds[blk];
-          else if (blk > 0) seed[u] = a.in[blk * 128 - 1];
-        }
+      if (WHAT == RED_MAXBITS && a.group > 1) {
+        x[u] = u32x4{0, 0, 0, 0};
+        for (uint32_t g = 0; g < a.group; ++g) x[u] |= *reinterpret_cast<const u32x4 *>(a.in + (bc * a.group + g) * 128 + 4 * k);
+      } else {
+        x[u] = stream_load(reinterpret_cast<const u32x4 *>(a.in + bc * 128 + 4 * k));
+      }
+      if constexpr (WHAT == RED_MAXBITSD1) {
+        // explicit offsets, or chained from the input: block k starts from in[128k-1], block 0 from seed0
+        const uint32_t *sp = a.seeds ? a.seeds + bc : a.in + (bc ? bc * 128 - 1 : 0);
+        const uint32_t s0 = *sp;
+        seed[u] = (a.seeds || bc) ? s0 : a.seed0;
       }
     }
 #pragma unroll
