@@ -358,6 +358,60 @@ __global__ __launch_bounds__(256) void k_pack_flex(PackArgs a) {
 //     prefetch from the decode waves themselves gains nothing: a wave keeps
 //     its slot until its last load has returned.)
 
+// Decode one already-loaded block per half-wave: LDS exchange, extraction, the
+// mode's arithmetic, one 16-byte store per thread.  `b` is B when B >= 0.
+template <int B, int MODE, int STORE = 0>
+__device__ __forceinline__ void unpack_finish(const u32x4 ld, const uint32_t b, const uint32_t seed, u32x4 *slot,
+                                              const int k, uint32_t *out_row) {
+  u32x4 v;
+  if constexpr (B == 0) {
+    v = u32x4{0, 0, 0, 0};
+  } else if constexpr (B == 32) {
+    v = ld;
+  } else {
+    wave_lds_fence();
+    slot[k] = ld;
+    wave_lds_fence();
+    const uint32_t p = (uint32_t)k * b, w = p >> 5, s = p & 31;
+    const u32x4 lo = slot[w], hi = slot[w + 1];
+    const uint32_t m = field_mask(b);
+    v.x = funnel(hi.x, lo.x, s) & m;
+    v.y = funnel(hi.y, lo.y, s) & m;
+    v.z = funnel(hi.z, lo.z, s) & m;
+    v.w = funnel(hi.w, lo.w, s) & m;
+  }
+  if constexpr (MODE == MODE_D1 && B != 32) {
+    u32x4 r = v;
+    r.y += r.x;
+    r.z += r.y;
+    r.w += r.z;
+    const uint32_t incl = half_scan_add(r.w);
+    const uint32_t before = seed + incl - r.w;
+    r.x += before;
+    r.y += before;
+    r.z += before;
+    r.w += before;
+    if constexpr (B < 0) {
+      const bool raw = b == 32;
+      v.x = raw ? v.x : r.x;
+      v.y = raw ? v.y : r.y;
+      v.z = raw ? v.z : r.z;
+      v.w = raw ? v.w : r.w;
+    } else {
+      v = r;
+    }
+  } else if constexpr (MODE == MODE_FOR && B != 32) {
+    const uint32_t add = (B < 0 && b == 32) ? 0u : seed;
+    v.x += add;
+    v.y += add;
+    v.z += add;
+    v.w += add;
+  }
+  if constexpr (STORE == 1) __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(out_row));
+  else if constexpr (STORE == 2) *reinterpret_cast<u32x4 *>(out_row) = v;
+  else stream_store(reinterpret_cast<u32x4 *>(out_row), v);
+}
+
 // Touch the 16-byte vectors that hold bytes [byte0, byte0 + NBYTES) of `base` with ordinary (cache-allocating)
 // loads, all issued back to back; vectors past the one holding `last_byte` re-read that one.  `base` needs no
 // alignment: addresses are rounded down to 16, which stays inside the 16-byte chunk the array starts in.
@@ -447,107 +501,10 @@ __global__ __launch_bounds__(BS) void k_unpack_fast(UnpackArgs a, uint32_t nwg =
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const size_t blk = first + 2 * (size_t)u;
-      u32x4 v;
-      if constexpr (B == 0) {
-        v = u32x4{0, 0, 0, 0};
-      } else if constexpr (B == 32) {
-        v = ld[u];
-      } else {
-        wave_lds_fence();
-        slot[k] = ld[u];
-        wave_lds_fence();
-        const uint32_t p = (uint32_t)k * b[u], w = p >> 5, s = p & 31;
-        const u32x4 lo = slot[w], hi = slot[w + 1];
-        const uint32_t m = field_mask(b[u]);
-        v.x = funnel(hi.x, lo.x, s) & m;
-        v.y = funnel(hi.y, lo.y, s) & m;
-        v.z = funnel(hi.z, lo.z, s) & m;
-        v.w = funnel(hi.w, lo.w, s) & m;
-      }
-      if constexpr (MODE == MODE_D1 && B != 32) {
-        u32x4 r = v;
-        r.y += r.x;
-        r.z += r.y;
-        r.w += r.z;
-        const uint32_t incl = half_scan_add(r.w);
-        const uint32_t before = seed[u] + incl - r.w;
-        r.x += before;
-        r.y += before;
-        r.z += before;
-        r.w += before;
-        if constexpr (B < 0) {
-          const bool raw = b[u] == 32;
-          v.x = raw ? v.x : r.x;
-          v.y = raw ? v.y : r.y;
-          v.z = raw ? v.z : r.z;
-          v.w = raw ? v.w : r.w;
-        } else {
-          v = r;
-        }
-      } else if constexpr (MODE == MODE_FOR && B != 32) {
-        const uint32_t add = (B < 0 && b[u] == 32) ? 0u : seed[u];
-        v.x += add;
-        v.y += add;
-        v.z += add;
-        v.w += add;
-      }
-      stream_store(reinterpret_cast<u32x4 *>(a.out + blk * 128 + 4 * k), v);
+      unpack_finish<B, MODE>(B != 0 ? ld[u] : u32x4{0, 0, 0, 0}, b[u], MODE != MODE_PLAIN ? seed[u] : 0u, slot, k,
+                             a.out + blk * 128 + 4 * k);
     }
   }
-}
-
-// Decode one already-loaded block per half-wave: LDS exchange, extraction, the
-// mode's arithmetic, one 16-byte store per thread.  `b` is B when B >= 0.
-template <int B, int MODE, int STORE = 0>
-__device__ __forceinline__ void unpack_finish(const u32x4 ld, const uint32_t b, const uint32_t seed, u32x4 *slot,
-                                              const int k, uint32_t *out_row) {
-  u32x4 v;
-  if constexpr (B == 0) {
-    v = u32x4{0, 0, 0, 0};
-  } else if constexpr (B == 32) {
-    v = ld;
-  } else {
-    wave_lds_fence();
-    slot[k] = ld;
-    wave_lds_fence();
-    const uint32_t p = (uint32_t)k * b, w = p >> 5, s = p & 31;
-    const u32x4 lo = slot[w], hi = slot[w + 1];
-    const uint32_t m = field_mask(b);
-    v.x = funnel(hi.x, lo.x, s) & m;
-    v.y = funnel(hi.y, lo.y, s) & m;
-    v.z = funnel(hi.z, lo.z, s) & m;
-    v.w = funnel(hi.w, lo.w, s) & m;
-  }
-  if constexpr (MODE == MODE_D1 && B != 32) {
-    u32x4 r = v;
-    r.y += r.x;
-    r.z += r.y;
-    r.w += r.z;
-    const uint32_t incl = half_scan_add(r.w);
-    const uint32_t before = seed + incl - r.w;
-    r.x += before;
-    r.y += before;
-    r.z += before;
-    r.w += before;
-    if constexpr (B < 0) {
-      const bool raw = b == 32;
-      v.x = raw ? v.x : r.x;
-      v.y = raw ? v.y : r.y;
-      v.z = raw ? v.z : r.z;
-      v.w = raw ? v.w : r.w;
-    } else {
-      v = r;
-    }
-  } else if constexpr (MODE == MODE_FOR && B != 32) {
-    const uint32_t add = (B < 0 && b == 32) ? 0u : seed;
-    v.x += add;
-    v.y += add;
-    v.z += add;
-    v.w += add;
-  }
-  if constexpr (STORE == 1) __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(out_row));
-  else if constexpr (STORE == 2) *reinterpret_cast<u32x4 *>(out_row) = v;
-  else stream_store(reinterpret_cast<u32x4 *>(out_row), v);
 }
 
 template <int B, int MODE, bool MASKED, int U, int BS>
