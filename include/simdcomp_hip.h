@@ -193,6 +193,28 @@ size_t simdcomp_hip_stream_index_workspace(size_t stream_bytes);
 int simdcomp_hip_stream_index(const void *d_stream, size_t stream_bytes, size_t max_blocks, uint8_t *d_bits,
                               uint64_t *d_payload_offsets, uint64_t *d_result, void *d_workspace, void *stream);
 
+/* compress() of example.c:56-75 (SIMDCOMP_HIP_D1: width from simdmaxbitsd1,
+ * simdpackwithoutmaskd1, offset = last value of the previous block, first
+ * offset `initvalue`) or varying_bit_width_compress() of :135-150
+ * (SIMDCOMP_HIP_PLAIN: maxbits, simdpackwithoutmask) as one call: widths,
+ * offsets scan and in-place pack enqueued back to back, no host
+ * synchronisation.  d_stream needs room for the worst case, 513 * nblocks
+ * bytes (what example.c:84 allocates); *d_stream_bytes (device memory)
+ * receives the length actually written.  d_workspace:
+ * simdcomp_hip_stream_compress_workspace(nblocks) bytes, 16-byte aligned. */
+size_t simdcomp_hip_stream_compress_workspace(size_t nblocks);
+int simdcomp_hip_stream_compress(int mode, uint32_t initvalue, const uint32_t *d_in, size_t nblocks, void *d_stream,
+                                 uint64_t *d_stream_bytes, void *d_workspace, void *stream);
+/* The decode loops of example.c:101-110 (SIMDCOMP_HIP_D1) and :170-175
+ * (SIMDCOMP_HIP_PLAIN) as one call: record index, chained offsets, in-place
+ * unpack.  d_result as for simdcomp_hip_stream_index; when the stream holds
+ * fewer than nblocks records the missing blocks decode as zero-width blocks
+ * (check d_result[0] == nblocks and d_result[2] == 0).  d_workspace:
+ * simdcomp_hip_stream_decode_workspace(stream_bytes, nblocks) bytes. */
+size_t simdcomp_hip_stream_decode_workspace(size_t stream_bytes, size_t nblocks);
+int simdcomp_hip_stream_decode(int mode, uint32_t initvalue, const void *d_stream, size_t stream_bytes, size_t nblocks,
+                               uint32_t *d_out, uint64_t *d_result, void *d_workspace, void *stream);
+
 /* ---- batched random access: many queries per launch -------------------------- */
 
 /* Blocks are addressed like everywhere else: uniform width (d_bits = NULL, block k

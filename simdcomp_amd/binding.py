@@ -40,6 +40,10 @@ DEVICE_API = {
     "simdcomp_hip_stream_unbuild": (C.c_int, [vp, vp, vp, sz, vp, vp]),
     "simdcomp_hip_stream_index_workspace": (sz, [sz]),
     "simdcomp_hip_stream_index": (C.c_int, [vp, sz, sz, vp, vp, vp, vp, vp]),
+    "simdcomp_hip_stream_compress_workspace": (sz, [sz]),
+    "simdcomp_hip_stream_compress": (C.c_int, [C.c_int, u32, vp, sz, vp, vp, vp, vp]),
+    "simdcomp_hip_stream_decode_workspace": (sz, [sz, sz]),
+    "simdcomp_hip_stream_decode": (C.c_int, [C.c_int, u32, vp, sz, sz, vp, vp, vp, vp]),
     "simdcomp_hip_select": (C.c_int, [C.c_int, u32, vp, vp, vp, vp, u32, C.c_int, vp, vp, sz, vp, vp]),
     "simdcomp_hip_search": (C.c_int, [C.c_int, u32, vp, vp, vp, vp, u32, C.c_int, vp, vp, vp, sz, vp, vp, vp, vp]),
     "simdcomp_hip_scand1": (C.c_int, [u32, vp, vp, vp, vp, u32, C.c_int, sz, vp, vp]),

@@ -208,6 +208,30 @@ def stream_index(stream, max_blocks, nbytes=None):
     return bits, off, res
 
 
+def stream_compress(mode, x, initvalue=0):
+    """example.c's compress() (D1) / varying_bit_width_compress() (PLAIN) -> (uint8 stream buffer, length as 1-element int64 tensor)."""
+    x = _i32(x)
+    nblocks = x.numel() // 128
+    buf = torch.empty(nblocks * 513 + 16, dtype=torch.uint8, device=x.device)
+    nbytes = torch.zeros(1, dtype=torch.int64, device=x.device)
+    ws = torch.empty(max(16, B.lib().simdcomp_hip_stream_compress_workspace(nblocks)), dtype=torch.uint8, device=x.device)
+    B.check(B.lib().simdcomp_hip_stream_compress(mode, _s32(initvalue), B.ptr(x), nblocks, B.ptr(buf), B.ptr(nbytes),
+                                                 B.ptr(ws), _stream()), "stream_compress")
+    return buf, nbytes
+
+
+def stream_decode(mode, stream, nblocks, initvalue=0, nbytes=None):
+    """example.c's decode loops -> (int32[nblocks*128], result int64[3] = records, payload bytes, status)."""
+    nbytes = stream.numel() if nbytes is None else nbytes
+    out = torch.empty(nblocks * 128, dtype=torch.int32, device=stream.device)
+    res = torch.zeros(3, dtype=torch.int64, device=stream.device)
+    ws = torch.empty(max(16, B.lib().simdcomp_hip_stream_decode_workspace(nbytes, nblocks)), dtype=torch.uint8,
+                     device=stream.device)
+    B.check(B.lib().simdcomp_hip_stream_decode(mode, _s32(initvalue), B.ptr(stream), nbytes, nblocks, B.ptr(out), B.ptr(res),
+                                               B.ptr(ws), _stream()), "stream_decode")
+    return out, res
+
+
 def select(mode, payload, slots, bit=0, bits=None, offsets=None, initvalues=None, initvalue=0, query_blocks=None,
            stream_layout=False):
     """Batched simdselectd1 / simdselectFOR: slots int32[nq] -> values int32[nq]."""

@@ -379,6 +379,64 @@ int simdcomp_hip_stream_index(const void *d_stream, size_t stream_bytes, size_t 
                     "stream index launch");
 }
 
+// ---- example.c's compress() and decode loops as one call each ----------------------------------------------------
+namespace {
+size_t up256(size_t x) { return (x + 255) / 256 * 256; }
+}  // namespace
+
+size_t simdcomp_hip_stream_compress_workspace(size_t nblocks) {
+  return up256(nblocks) + up256(8 * nblocks) + 256 + up256(sc::scan_workspace_bytes(nblocks)) + 256;
+}
+
+int simdcomp_hip_stream_compress(int mode, uint32_t initvalue, const uint32_t *d_in, size_t nblocks, void *d_stream,
+                                 uint64_t *d_stream_bytes, void *d_workspace, void *stream) {
+  if (mode != SIMDCOMP_HIP_D1 && mode != SIMDCOMP_HIP_PLAIN) return fail(SIMDCOMP_HIP_EMODE, "mode must be D1 or PLAIN");
+  if (!d_stream_bytes) return fail(SIMDCOMP_HIP_ENULL, "d_stream_bytes is NULL");
+  if (nblocks == 0) return hip_result(hipMemsetAsync(d_stream_bytes, 0, sizeof(uint64_t), as_stream(stream)), "memset");
+  if (!d_in || !d_stream || !d_workspace) return fail(SIMDCOMP_HIP_ENULL, "NULL pointer");
+  if (!aligned16(d_in) || !aligned16(d_workspace)) return fail(SIMDCOMP_HIP_EALIGN, "pointer not 16-byte aligned");
+  uint8_t *ws = static_cast<uint8_t *>(d_workspace);
+  uint8_t *bits = ws;
+  uint64_t *off = reinterpret_cast<uint64_t *>(ws + up256(nblocks));
+  uint64_t *total = reinterpret_cast<uint64_t *>(ws + up256(nblocks) + up256(8 * nblocks));
+  void *scan_ws = ws + up256(nblocks) + up256(8 * nblocks) + 256;
+  int rc = mode == SIMDCOMP_HIP_D1 ? simdcomp_hip_maxbitsd1(initvalue, nullptr, d_in, nblocks, bits, nullptr, stream)
+                                   : simdcomp_hip_maxbits(d_in, nblocks, bits, stream);
+  if (rc) return rc;
+  if ((rc = simdcomp_hip_payload_offsets(bits, nblocks, off, total, scan_ws, stream))) return rc;
+  if ((rc = simdcomp_hip_pack_stream(mode, 0, initvalue, nullptr, d_in, d_stream, off, bits, nblocks, nullptr, stream))) return rc;
+  return hip_result(sc::launch_stream_bytes(total, nblocks, d_stream_bytes, as_stream(stream)), "stream bytes launch");
+}
+
+size_t simdcomp_hip_stream_decode_workspace(size_t stream_bytes, size_t nblocks) {
+  return up256(nblocks) + up256(8 * nblocks) + up256(4 * nblocks) + up256(sc::stream_index_workspace_bytes(stream_bytes)) +
+         up256(sc::chain_workspace_bytes(nblocks)) + 256;
+}
+
+int simdcomp_hip_stream_decode(int mode, uint32_t initvalue, const void *d_stream, size_t stream_bytes, size_t nblocks,
+                               uint32_t *d_out, uint64_t *d_result, void *d_workspace, void *stream) {
+  if (mode != SIMDCOMP_HIP_D1 && mode != SIMDCOMP_HIP_PLAIN) return fail(SIMDCOMP_HIP_EMODE, "mode must be D1 or PLAIN");
+  if (!d_result) return fail(SIMDCOMP_HIP_ENULL, "d_result is NULL");
+  if (nblocks == 0) return hip_result(hipMemsetAsync(d_result, 0, 3 * sizeof(uint64_t), as_stream(stream)), "memset");
+  if (!d_stream || !d_out || !d_workspace) return fail(SIMDCOMP_HIP_ENULL, "NULL pointer");
+  if (!aligned16(d_out) || !aligned16(d_workspace)) return fail(SIMDCOMP_HIP_EALIGN, "pointer not 16-byte aligned");
+  uint8_t *ws = static_cast<uint8_t *>(d_workspace);
+  uint8_t *bits = ws;
+  uint64_t *off = reinterpret_cast<uint64_t *>(ws + up256(nblocks));
+  uint32_t *seeds = reinterpret_cast<uint32_t *>(ws + up256(nblocks) + up256(8 * nblocks));
+  uint8_t *index_ws = ws + up256(nblocks) + up256(8 * nblocks) + up256(4 * nblocks);
+  uint8_t *chain_ws = index_ws + up256(sc::stream_index_workspace_bytes(stream_bytes));
+  // a stream with fewer records than nblocks leaves the rest as zero-width blocks at offset 0 (d_result[0] tells)
+  if (hipError_t e = hipMemsetAsync(ws, 0, up256(nblocks) + up256(8 * nblocks), as_stream(stream))) return hip_result(e, "memset");
+  int rc = simdcomp_hip_stream_index(d_stream, stream_bytes, nblocks, bits, off, d_result, index_ws, stream);
+  if (rc) return rc;
+  if (mode == SIMDCOMP_HIP_D1) {
+    if ((rc = simdcomp_hip_chain_offsets(initvalue, d_stream, off, bits, nblocks, 1, seeds, chain_ws, stream))) return rc;
+    return simdcomp_hip_unpack_stream(SIMDCOMP_HIP_D1, seeds, d_stream, off, bits, d_out, nblocks, stream);
+  }
+  return simdcomp_hip_unpack_stream(SIMDCOMP_HIP_PLAIN, nullptr, d_stream, off, bits, d_out, nblocks, stream);
+}
+
 namespace {
 int do_query(int mode, int what, uint32_t initvalue, const uint32_t *d_initvalues, const void *d_payload,
              const uint64_t *d_payload_offsets, const uint8_t *d_bits, uint32_t bit, int stream_layout, sc::QueryArgs a,

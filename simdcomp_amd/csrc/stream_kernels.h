@@ -21,6 +21,9 @@ hipError_t launch_stream_build(const void *arena, const uint64_t *off, const uin
 hipError_t launch_stream_unbuild(const uint8_t *stream, const uint64_t *off, const uint8_t *bits, size_t nblocks, void *arena,
                                  hipStream_t st);
 
+// *out = *payload_bytes + nblocks: the length of the stream that holds nblocks records
+hipError_t launch_stream_bytes(const uint64_t *payload_bytes, size_t nblocks, uint64_t *out, hipStream_t st);
+
 // --- finding the records of a stream whose widths are only known from the stream itself ---------------------------
 size_t stream_index_workspace_bytes(size_t stream_bytes);
 // result[0] = records found, result[1] = arena bytes (16 * sum of widths), result[2] = 0 when the stream parsed

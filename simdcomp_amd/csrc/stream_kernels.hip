@@ -471,6 +471,13 @@ __global__ __launch_bounds__(EMIT_THREADS) void k_index_emit(const uint8_t *stre
   }
 }
 
+__global__ void k_stream_bytes(const uint64_t *payload_bytes, uint64_t nblocks, uint64_t *out) { *out = *payload_bytes + nblocks; }
+
+hipError_t launch_stream_bytes(const uint64_t *payload_bytes, size_t nblocks, uint64_t *out, hipStream_t st) {
+  hipLaunchKernelGGL(k_stream_bytes, dim3(1), dim3(1), 0, st, payload_bytes, (uint64_t)nblocks, out);
+  return hipGetLastError();
+}
+
 static size_t idx_chunks(size_t nbytes) { return (nbytes + IDX_CHUNK - 1) / IDX_CHUNK; }
 
 size_t stream_index_workspace_bytes(size_t nbytes) {

@@ -209,3 +209,34 @@ def test_large_stream_2p27(dev):
     assert torch.equal(chained, seeds)
     out = dev.unpack_stream(D1, stream2, ibits, ioff, nblk, initvalues=chained)
     assert int(dev.checksum(out, other=ids)[1].item()) == 0
+
+
+@pytest.mark.parametrize("d1", [True, False])
+def test_one_call_compress_and_decode(dev, orc, d1):
+    """simdcomp_hip_stream_compress / _decode: example.c's compress() and decode loop, one call each."""
+    import torch
+
+    g = G.load("stream.npz")
+    nblk = int(g["nblocks"])
+    want = g["d1" if d1 else "plain"]
+    x = G.stream_corpus(900, nblk)
+    mode = D1 if d1 else PLAIN
+    buf, nbytes = dev.stream_compress(mode, to_dev(x))
+    n = int(nbytes.item())
+    assert n == want.size and np.array_equal(buf[:n].cpu().numpy(), want)
+    out, res = dev.stream_decode(mode, to_dev(want), nblk)
+    assert res.tolist() == [nblk, want.size - nblk, 0] and np.array_equal(u32(out), x)
+    # another start offset, a larger corpus, a stream that sits at an odd address
+    for nb, init in ((1, 5), (4099, 0x80000001)):
+        x = G.stream_corpus(31 + nb, nb)
+        want = orc.stream_compress(x, d1=d1, initvalue=init)
+        buf, nbytes = dev.stream_compress(mode, to_dev(x), initvalue=init)
+        assert int(nbytes.item()) == want.size and np.array_equal(buf[:want.size].cpu().numpy(), want)
+        shifted = torch.zeros(want.size + 7, dtype=torch.uint8, device="cuda")
+        shifted[7:] = to_dev(want)
+        out, res = dev.stream_decode(mode, shifted[7:], nb, initvalue=init)
+        assert res.tolist() == [nb, want.size - nb, 0]
+        assert np.array_equal(u32(out), orc.stream_decode(want, nb, d1=d1, initvalue=init))
+    # asking for more blocks than the stream holds: reported, the surplus decodes as zero-width blocks
+    out, res = dev.stream_decode(mode, to_dev(want), nb + 3, initvalue=init)
+    assert res.tolist()[0] == nb and np.array_equal(u32(out)[: nb * 128], orc.stream_decode(want, nb, d1=d1, initvalue=init))
