@@ -240,3 +240,43 @@ def test_one_call_compress_and_decode(dev, orc, d1):
     # asking for more blocks than the stream holds: reported, the surplus decodes as zero-width blocks
     out, res = dev.stream_decode(mode, to_dev(want), nb + 3, initvalue=init)
     assert res.tolist()[0] == nb and np.array_equal(u32(out)[: nb * 128], orc.stream_decode(want, nb, d1=d1, initvalue=init))
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_index_adversarial_payloads(dev, orc, seed):
+    """Streams built byte by byte: payload bytes that look like width bytes (half of them are <= 32, many are 0)
+    start false chains everywhere; lengths chosen so that records end exactly on, just before and just after the
+    16 KiB chunk and 4 MiB group boundaries of the index."""
+    import torch
+
+    rng = np.random.default_rng(seed)
+    for target in (16384 - 1, 16384, 16384 + 1, 3 * 16384, 256 * 16384 - 7, 256 * 16384, 256 * 16384 + 513, 2 * 256 * 16384 + 5):
+        widths = []
+        total = 0
+        while True:
+            w = int(rng.choice([0, 0, 1, 2, 3, 5, 8, 13, 20, 31, 32]))
+            if total + 1 + 16 * w > target:
+                break
+            widths.append(w)
+            total += 1 + 16 * w
+        while total < target:  # top up with zero-width records so that the stream is exactly `target` bytes long
+            widths.append(0)
+            total += 1
+        widths = np.array(widths, np.uint8)
+        nblk = widths.size
+        pos = np.concatenate([[0], np.cumsum(1 + 16 * widths.astype(np.int64))])[:-1]
+        stream = rng.integers(0, 256, target, dtype=np.uint8)
+        low = rng.random(target) < 0.5
+        stream[low] = rng.integers(0, 33, int(low.sum()), dtype=np.uint8)
+        stream[rng.random(target) < 0.2] = 0
+        stream[pos] = widths
+        n, wbits, woff, status = orc.stream_walk(stream, nblk)
+        assert (n, status) == (nblk, 0) and np.array_equal(wbits, widths)
+        bits, off, res = dev.stream_index(to_dev(stream), nblk)
+        assert res.tolist() == [nblk, target - nblk, 0], target
+        assert np.array_equal(bits.cpu().numpy(), widths), target
+        assert np.array_equal(off.cpu().numpy().view(np.uint64), woff), target
+        # decode in place (plain): equals the CPU loop over the same bytes
+        if nblk <= 40000:
+            out = dev.unpack_stream(PLAIN, to_dev(np.concatenate([stream, np.zeros(16, np.uint8)]))[:target], bits, off, nblk)
+            assert np.array_equal(u32(out), orc.stream_decode(stream, nblk, d1=False))
