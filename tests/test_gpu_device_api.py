@@ -320,3 +320,42 @@ def test_partition_and_checksum(dev):
     y[99999] ^= 4
     assert dev.checksum(x, other=y)[1].item() == 2
     assert dev.checksum(y)[0].item() != whole[0].item()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_randomised_shapes(dev, orc, seed):
+    """Random block counts (around the workgroup, prefetch-group and launch granularities), modes, widths and
+    seed conventions against the oracle."""
+    import torch
+
+    rng = np.random.default_rng(1000 + seed)
+    for _ in range(12):
+        nblk = int(rng.choice([1, 3, 8, 9, 127, 128, 129, 136, 137, 2047, 2048, 2177, 5000, 20001]))
+        bit = int(rng.integers(0, 33))
+        mode = ["plain", "d1", "for"][int(rng.integers(0, 3))]
+        masked = bool(rng.integers(0, 2)) and mode != "for"
+        wild = bool(rng.integers(0, 2))
+        x = synth.rand_u32(int(rng.integers(1, 1 << 30)), nblk * 128)
+        if not wild:
+            x = x & synth.mask(bit) if bit < 32 else x
+            if mode == "d1":
+                x = (np.cumsum(x.astype(np.uint64)) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        seeds = synth.rand_u32(int(rng.integers(1, 1 << 30)), nblk) if mode != "plain" else None
+        if mode == "d1" and bool(rng.integers(0, 2)):
+            seeds = synth.block_offsets(x, 11)  # chained from the input
+            got = dev.packd1(to_dev(x), bit, initvalue=11, masked=masked)
+        elif mode == "d1":
+            got = dev.packd1(to_dev(x), bit, initvalues=to_dev(seeds), masked=masked)
+        elif mode == "for":
+            got = dev.packFOR(to_dev(seeds), to_dev(x), bit)
+        else:
+            got = dev.pack(to_dev(x), bit, masked=masked)
+        want = orc.batch_pack(mode, x, bit, seeds=seeds, masked=masked)
+        assert np.array_equal(to_np(got), want), (mode, bit, nblk, masked, wild)
+        if mode == "d1":
+            dec = dev.unpackd1(to_dev(seeds), got, nblk, bit)
+        elif mode == "for":
+            dec = dev.unpackFOR(to_dev(seeds), got, nblk, bit)
+        else:
+            dec = dev.unpack(got, nblk, bit)
+        assert np.array_equal(to_np(dec), orc.batch_unpack(mode, want, nblk, bit, seeds=seeds)), (mode, bit, nblk)
