@@ -487,8 +487,11 @@ __global__ __launch_bounds__(BS) void k_unpack_fast(UnpackArgs a, uint32_t nwg =
         const uint32_t last = b[u] ? b[u] - 1 : 0;
         // stream layout: the record's width byte and the k width bytes before it sit in front of the payload
         const uint64_t skip = a.stream_layout ? a.block_base + blk + 1 : 0;
-        const u32x4_u *in_payload = reinterpret_cast<const u32x4_u *>(
-            static_cast<const uint8_t *>(a.payload) + o[u] + skip + 16 * ((uint32_t)k < last ? (uint32_t)k : last));
+        uintptr_t at = reinterpret_cast<uintptr_t>(a.payload) + o[u] + skip + 16 * ((uint32_t)k < last ? (uint32_t)k : last);
+        // the lanes past the payload's end only keep the access pattern branch-free: they read the 16-byte line that
+        // holds the start of its last vector (32 lanes on one unaligned address coalesce worse than on an aligned one)
+        at = (uint32_t)k > last ? (at & ~(uintptr_t)15) : at;
+        const u32x4_u *in_payload = reinterpret_cast<const u32x4_u *>(at);
         // a zero-width block has no payload: read (and ignore) its own output area instead
         const u32x4_u *in_output = reinterpret_cast<const u32x4_u *>(a.out + blk * 128);
         src[u] = b[u] ? in_payload : in_output;

@@ -54,8 +54,9 @@ __global__ __launch_bounds__(256) void k_block_sums(const uint8_t *payload, cons
   for (int u = 0; u < U; ++u) {
     b[u] = b[u] > 32 ? 32 : b[u];
     const uint32_t last = b[u] ? b[u] - 1 : 0;
-    const u32x4_u *in_payload = reinterpret_cast<const u32x4_u *>(payload + o[u] + 16 * ((uint32_t)k < last ? (uint32_t)k : last));
-    ld[u] = *(b[u] ? in_payload : reinterpret_cast<const u32x4_u *>(sums));
+    uintptr_t at = reinterpret_cast<uintptr_t>(payload) + o[u] + 16 * ((uint32_t)k < last ? (uint32_t)k : last);
+    at = (uint32_t)k > last ? (at & ~(uintptr_t)15) : at;  // idle lanes: an aligned address coalesces better
+    ld[u] = *(b[u] ? reinterpret_cast<const u32x4_u *>(at) : reinterpret_cast<const u32x4_u *>(sums));
   }
 #pragma unroll
   for (int u = 0; u < U; ++u) {

@@ -29,5 +29,24 @@ int main() {
     if (o[so + 16 * n] != 0xEE) ++bad;
   }
   printf("unaligned dwordx4 copy: %s (%d bad)\n", bad ? "WRONG" : "ok", bad);
+  // rate of a 1 GiB copy with the load side, the store side, or neither at an odd byte address
+  const size_t big = (size_t)1 << 30;
+  uint8_t *bs, *bd;
+  CK(hipMalloc(&bs, big + 64)); CK(hipMalloc(&bd, big + 64));
+  CK(hipMemset(bs, 1, big + 64));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  const int shifts[4][2] = {{0, 0}, {1, 0}, {0, 1}, {7, 3}};
+  for (auto &sh : shifts) {
+    float best = 1e9f;
+    for (int r = 0; r < 6; ++r) {
+      CK(hipEventRecord(e0));
+      hipLaunchKernelGGL(k_copy, dim3((unsigned)(big / 16 / 256)), dim3(256), 0, 0, bs, bd, sh[0], sh[1], (int)(big / 16));
+      CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      if (r && ms < best) best = ms;
+    }
+    printf("copy 1 GiB, load shift %d store shift %d: %.3f ms  %.0f GB/s\n", sh[0], sh[1], best, 2.0 * big / best / 1e6);
+  }
   return bad != 0;
 }
