@@ -341,11 +341,15 @@ __global__ __launch_bounds__(IDX_THREADS) void k_index_candidates(const uint8_t 
         w[i] = t == IDX_INVALID ? IDX_INVALID : ((((w[i] >> 16) + (t >> 16)) << 16) | (t & 0xFFFF));
       }
     }
-    __syncthreads();
+    bool any = false;
+#pragma unroll
+    for (int i = 0; i < PER_THREAD; ++i) any = any || link[i];
+    const int pending = __syncthreads_or(any);  // also the barrier between this round's reads and writes
 #pragma unroll
     for (int i = 0; i < PER_THREAD; ++i)
       if (link[i]) res[threadIdx.x + i * IDX_THREADS] = w[i];
     __syncthreads();
+    if (!pending) break;  // no links left (typical data resolves in two or three rounds)
   }
   for (uint32_t f = threadIdx.x; f < IDX_CAND; f += IDX_THREADS) {
     const uint32_t w = res[f];
