@@ -355,6 +355,10 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK, 4), "traffic": measured_traffic(nblocks),
                          "algorithmic_bytes_per_launch": tot_bytes / len(WIDTHS),
+                         "traffic_note": "L2<->fabric bytes from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                                         "(reads = 2 x FETCH_SIZE on gfx950); widths 1..7 fetch their payload twice at this "
+                                         "level (prefetch workgroup + decode workgroup, second copy from the Infinity Cache), "
+                                         "widths >= 8 are within 4 % of algorithmic",
                          "kernel": "sc::k_unpack_fast<b, d1> (one instantiation per width), aggregate over b=1..32",
                          "bytes_per_block": "512 + 16*b + 4",
                          "min_frac": min(v["frac"] for v in table.values()),
