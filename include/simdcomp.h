@@ -25,6 +25,7 @@
 #define SIMDCOMP_H_
 
 #include <emmintrin.h> /* __m128i: the compressed stream is addressed in 16-byte vectors */
+#include <string.h>    /* the reference's headers bring it in (simdbitpacking.h:13); its callers rely on that */
 #include <stddef.h>
 #include <stdint.h>
 
@@ -88,6 +89,8 @@ int simdsearchwithlengthFOR(uint32_t initvalue, const __m128i *in, uint32_t bit,
  * 256- / 512-integer blocks with 8 / 16 interleaved lanes (data packed by the reference's AVX paths).  The vector
  * types exist only when the including program is compiled for those ISAs, as in the reference's headers; other
  * programs see the same functions with untyped pointers. */
+enum { AVXBlockSize = 256 };    /* avxbitpacking.h:19 */
+enum { AVX512BlockSize = 512 }; /* avx512bitpacking.h */
 #if defined(__AVX2__) && !defined(SIMDCOMP_HIP_BUILDING)
 #include <immintrin.h>
 uint32_t avxmaxbits(const uint32_t *begin);                                    /* avxbitpacking.h:22 */
