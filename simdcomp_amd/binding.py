@@ -117,6 +117,14 @@ def load():
         raise ImportError(
             f"{LIB_PATH} not found: build it with `make -C simdcomp_amd/csrc` "
             "(or __graft_entry__.build()); there is no fallback implementation")
+    # PyTorch ships its own copy of the HIP runtime under the same soname (libamdhip64.so.7) as the system one this
+    # library is linked to, and the dynamic loader keeps whichever comes first for the whole process.  torch cannot
+    # start on the system copy ("No HIP GPUs are available"), this library runs on either: so in a process that has
+    # torch installed, let torch load its runtime first.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for table in (DEVICE_API, HOST_API):
         for name, (res, args) in table.items():

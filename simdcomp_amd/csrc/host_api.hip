@@ -14,6 +14,7 @@
 #include <stdlib.h>
 
 #include <mutex>
+#include <string.h>
 
 #include "../../include/simdcomp.h"
 #include "../../include/simdcomp_hip.h"
@@ -36,6 +37,8 @@ void ckapi(int rc, const char *where) {
   if (rc != 0) die(where, simdcomp_hip_last_error());
 }
 
+constexpr size_t ZC_BYTES = 64 << 10;  // operands up to this size take the mapped-host-buffer path
+
 struct Staging {
   std::mutex mu;
   bool ready = false;
@@ -44,6 +47,9 @@ struct Staging {
   void *out[2] = {nullptr, nullptr};
   size_t in_cap[2] = {0, 0}, out_cap[2] = {0, 0};
   uint32_t *result4 = nullptr;  // device scratch for whole-array reductions
+  // Small operands skip the copies: two host buffers that the GPU maps; the kernels read and write them in place
+  // over PCIe and the call costs one launch and one synchronisation instead of two copies on top of those.
+  uint8_t *zin = nullptr, *zout = nullptr;
 
   void init() {
     if (ready) return;
@@ -52,6 +58,8 @@ struct Staging {
     if (n <= 0) die("device discovery", "no HIP device");
     for (int i = 0; i < 2; ++i) ck(hipStreamCreateWithFlags(&stream[i], hipStreamNonBlocking), "hipStreamCreate");
     ck(hipMalloc(reinterpret_cast<void **>(&result4), 64), "hipMalloc");
+    ck(hipHostMalloc(reinterpret_cast<void **>(&zin), ZC_BYTES + 128, hipHostMallocMapped | hipHostMallocCoherent), "hipHostMalloc");
+    ck(hipHostMalloc(reinterpret_cast<void **>(&zout), ZC_BYTES + 128, hipHostMallocMapped | hipHostMallocCoherent), "hipHostMalloc");
     ready = true;
   }
 
@@ -72,6 +80,7 @@ struct Staging {
       out_cap[slot] = out_bytes;
     }
   }
+  uint8_t *zi() { return zin + 16; }  // 16 bytes in front, as for din()
   uint8_t *din(int slot) { return static_cast<uint8_t *>(in[slot]) + 16; }
   uint8_t *dout(int slot) { return static_cast<uint8_t *>(out[slot]); }
 };
@@ -95,40 +104,40 @@ void block_pack(int mode, bool masked, uint32_t initvalue, const uint32_t *in, v
   if (bit > 32) return;  // the reference's switch falls through and does nothing
   Staging &s = staging();
   std::lock_guard<std::mutex> lock(s.mu);
-  s.reserve(0, 512 * groups, 512 * groups);
+  s.init();
   hipStream_t st = s.stream[0];
-  h2d(s.din(0), in, 512 * (size_t)groups, st);
+  memcpy(s.zi(), in, 512 * (size_t)groups);
   sc::PackArgs a{};
-  a.in = reinterpret_cast<const uint32_t *>(s.din(0));
-  a.payload = s.dout(0);
+  a.in = reinterpret_cast<const uint32_t *>(s.zi());
+  a.payload = s.zout;
   a.nblocks = groups;
   a.length = 128 * (size_t)groups;
   a.bit = bit;
   a.seed0 = initvalue;  // seeds == nullptr: block 0 of a chained d1 stream / uniform frame base
   a.lane_groups = groups;
   ck(sc::launch_pack(mode, masked, false, a, st), "pack launch");
-  d2h(out, s.dout(0), 16 * (size_t)bit * groups, st);
   ck(hipStreamSynchronize(st), "hipStreamSynchronize");
+  memcpy(out, s.zout, 16 * (size_t)bit * groups);
 }
 
 void block_unpack(int mode, uint32_t initvalue, const void *in, uint32_t *out, uint32_t bit, uint32_t groups = 1) {
   if (bit > 32) return;
   Staging &s = staging();
   std::lock_guard<std::mutex> lock(s.mu);
-  s.reserve(0, 512 * groups, 512 * groups);
+  s.init();
   hipStream_t st = s.stream[0];
-  h2d(s.din(0), in, 16 * (size_t)bit * groups, st);
+  memcpy(s.zi(), in, 16 * (size_t)bit * groups);
   sc::UnpackArgs a{};
-  a.payload = s.din(0);
-  a.out = reinterpret_cast<uint32_t *>(s.dout(0));
+  a.payload = s.zi();
+  a.out = reinterpret_cast<uint32_t *>(s.zout);
   a.nblocks = groups;
   a.length = 128 * (size_t)groups;
   a.bit = bit;
   a.seed0 = initvalue;
   a.lane_groups = groups;
   ck(sc::launch_unpack(mode, false, a, st), "unpack launch");
-  d2h(out, s.dout(0), 512 * (size_t)groups, st);
   ck(hipStreamSynchronize(st), "hipStreamSynchronize");
+  memcpy(out, s.zout, 512 * (size_t)groups);
 }
 
 // ---- whole-array reductions ----------------------------------------------------
@@ -141,6 +150,14 @@ void reduce_host(const uint32_t *in, size_t length, uint32_t initvalue, uint32_t
     std::lock_guard<std::mutex> lock(s.mu);
     s.init();
     hipStream_t st = s.stream[0];
+    if (length * 4 <= ZC_BYTES) {
+      // the input is read in place; the four results are accumulated with device atomics and stay in device memory
+      memcpy(s.zi(), in, length * 4);
+      ckapi(simdcomp_hip_reduce_length(reinterpret_cast<const uint32_t *>(s.zi()), length, initvalue, s.result4, st), "reduce");
+      d2h(r, s.result4, 16, st);
+      ck(hipStreamSynchronize(st), "hipStreamSynchronize");
+      return;
+    }
     for (size_t done = 0; done < length; done += PIECE) {
       const size_t n = length - done < PIECE ? length - done : PIECE;
       s.reserve(0, n * 4, 0);
@@ -171,6 +188,17 @@ void *pack_length_host(int kind, uint32_t initvalue, const uint32_t *in, size_t 
   Staging &s = staging();
   std::lock_guard<std::mutex> lock(s.mu);
   s.init();
+  if (length * 4 <= ZC_BYTES) {
+    const size_t nbytes = simdcomp_hip_compressedbytes(length, bit);
+    hipStream_t st = s.stream[0];
+    memcpy(s.zi(), in, length * 4);
+    const uint32_t *z_in = reinterpret_cast<const uint32_t *>(s.zi());
+    if (kind == 0) ckapi(simdcomp_hip_pack_length(z_in, length, s.zout, bit, st), "pack_length");
+    else ckapi(simdcomp_hip_packFOR_length(initvalue, z_in, length, s.zout, bit, 0, st), "packFOR_length");
+    ck(hipStreamSynchronize(st), "hipStreamSynchronize");
+    memcpy(o, s.zout, nbytes);
+    return o + nbytes;
+  }
   size_t piece_index = 0;
   for (size_t done = 0; done < length; done += PIECE, ++piece_index) {
     const int slot = (int)(piece_index & 1);
@@ -200,6 +228,17 @@ const void *unpack_length_host(int kind, uint32_t initvalue, const void *in, siz
   Staging &s = staging();
   std::lock_guard<std::mutex> lock(s.mu);
   s.init();
+  if (length * 4 <= ZC_BYTES) {
+    const size_t nbytes = simdcomp_hip_compressedbytes(length, bit);
+    hipStream_t st = s.stream[0];
+    memcpy(s.zi(), p, nbytes);
+    uint32_t *z_out = reinterpret_cast<uint32_t *>(s.zout);
+    if (kind == 0) ckapi(simdcomp_hip_unpack_length(s.zi(), length, z_out, bit, st), "unpack_length");
+    else ckapi(simdcomp_hip_unpackFOR_length(initvalue, s.zi(), length, z_out, bit, st), "unpackFOR_length");
+    ck(hipStreamSynchronize(st), "hipStreamSynchronize");
+    memcpy(out, z_out, length * 4);
+    return p + nbytes;
+  }
   size_t piece_index = 0;
   for (size_t done = 0; done < length; done += PIECE, ++piece_index) {
     const int slot = (int)(piece_index & 1);
