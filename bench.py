@@ -176,9 +176,37 @@ def cpu_baseline(log2n=26, reps=3):
         avx2 = {"value": total / ta, "unit": "int32/s", "cores": 1, "what": "avxunpack (plain, 256-integer blocks)"}
     callers = cpu_callers(orc, lib if kind == "reference" else orc)
     return {"value": total / t1, "unit": "int32/s", "cores": 1, "kind": kind, "callers": callers,
+            "stock_benchmark": stock_benchmark(),
             "sample": f"simdunpackd1 over 2^{log2n} ints (out of cache) at each b=1..32, best of {reps}, "
                       f"{'oracle/_ref built -O3 -msse4.1' if kind == 'reference' else 'scalar restatement'}",
             "all_cores": {"value": total / tn, "cores": ncores}, "avx2_comparator": avx2}
+
+
+def stock_benchmark():
+    """The reference's own benchmarks/bitpackingbenchmark.c (one 128-integer block in cache, best of 500 calls, cycles
+    per integer including its rdtsc/cpuid bracket), linked with the reference's own routines: oracle/_ref/
+    bitpackingbenchmark_ref.  Mean over b=1..32 of each column; None when the binary was not built."""
+    import subprocess
+
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle", "_ref", "bitpackingbenchmark_ref")
+    if not os.path.exists(exe):
+        return None
+    try:
+        text = subprocess.run([exe], capture_output=True, text=True, timeout=60).stdout
+    except Exception as e:  # pragma: no cover
+        return {"error": str(e)}
+    res, name = {}, None
+    for line in text.splitlines():
+        if line.startswith("# --- "):
+            name = line[6:].strip()
+            res[name] = []
+        elif name and line[:1].isdigit():
+            f = line.split()
+            if len(f) >= 3:
+                res[name].append((float(f[1]), float(f[2])))
+    return {k: {"pack_cycles_per_int": round(sum(p for p, _ in v) / len(v), 3),
+                "unpack_cycles_per_int": round(sum(u for _, u in v) / len(v), 3), "widths": len(v)}
+            for k, v in res.items() if v}
 
 
 def cpu_callers(orc, codec, log2n=24):
