@@ -176,10 +176,20 @@ def cpu_baseline(log2n=26, reps=3):
         avx2 = {"value": total / ta, "unit": "int32/s", "cores": 1, "what": "avxunpack (plain, 256-integer blocks)"}
     callers = cpu_callers(orc, lib if kind == "reference" else orc)
     return {"value": total / t1, "unit": "int32/s", "cores": 1, "kind": kind, "callers": callers,
-            "stock_benchmark": stock_benchmark(),
+            "stock_benchmark": stock_benchmark(), "cpu_model": cpu_model(),
             "sample": f"simdunpackd1 over 2^{log2n} ints (out of cache) at each b=1..32, best of {reps}, "
                       f"{'oracle/_ref built -O3 -msse4.1' if kind == 'reference' else 'scalar restatement'}",
             "all_cores": {"value": total / tn, "cores": ncores}, "avx2_comparator": avx2}
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
 
 
 def stock_benchmark():
