@@ -656,10 +656,25 @@ __global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
         x[u] = stream_load(reinterpret_cast<const u32x4 *>(a.in + bc * 128 + 4 * k));
       }
       if constexpr (WHAT == RED_MAXBITSD1) {
-        // explicit offsets, or chained from the input: block k starts from in[128k-1], block 0 from seed0
-        const uint32_t *sp = a.seeds ? a.seeds + bc : a.in + (bc ? bc * 128 - 1 : 0);
-        const uint32_t s0 = *sp;
-        seed[u] = (a.seeds || bc) ? s0 : a.seed0;
+        // explicit offsets, or chained from the input: block k starts from in[128k-1], block 0 from seed0.  Chained,
+        // only the wave's first block reads it from memory: the others find it in the wave (below)
+        if (a.seeds || u == 0) {
+          const uint32_t *sp = a.seeds ? a.seeds + bc : a.in + (bc ? bc * 128 - 1 : 0);
+          const uint32_t s0 = *sp;
+          seed[u] = (a.seeds || bc) ? s0 : a.seed0;
+        }
+      }
+    }
+    if constexpr (WHAT == RED_MAXBITSD1) {
+      if (!a.seeds) {
+        // the wave's blocks are consecutive, even ones in the low half: an odd block's predecessor ends in lane 31
+        // of the same step, an even block's in lane 63 of the step before
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const uint32_t lo_last = (uint32_t)__builtin_amdgcn_readlane((int)x[u].w, 31);
+          const uint32_t up_last = u ? (uint32_t)__builtin_amdgcn_readlane((int)x[u - 1].w, 63) : seed[0];
+          seed[u] = h ? lo_last : up_last;
+        }
       }
     }
 #pragma unroll
@@ -866,7 +881,10 @@ static int grid_for(size_t nblocks, int U) {
 }
 
 constexpr int FLEX_U = 2;
-constexpr int REDUCE_U = 4;
+#ifndef SC_REDUCE_U
+#define SC_REDUCE_U 4
+#endif
+constexpr int REDUCE_U = SC_REDUCE_U;
 
 // Workgroup shape of the one-shot decoders, from a sweep of (threads, steps)
 // at every width with 2^30 integers: the best shapes write 4 KiB (narrow
