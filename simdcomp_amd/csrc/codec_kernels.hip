@@ -424,7 +424,7 @@ __device__ __forceinline__ void touch_bytes(const void *base, size_t byte0, size
   for (int t = 0; t < TRIPS; ++t) {
     uintptr_t v = v0 + (uintptr_t)t * BS + threadIdx.x;
     v = v < vlast ? v : vlast;
-    acc |= *reinterpret_cast<const u32x4 *>(v << 4);
+    acc |= load_global_at(v << 4);
   }
 }
 
@@ -470,17 +470,26 @@ __global__ __launch_bounds__(BS) void k_unpack_fast(UnpackArgs a, uint32_t nwg =
       if constexpr (B >= 0) {
         b[u] = B;
         src[u] = reinterpret_cast<const u32x4_u *>(payload + blk * (size_t)B + (k < B ? k : (B ? B - 1 : 0)));
-      } else {
-        b[u] = a.bits[blk];
       }
-      if constexpr (MODE != MODE_PLAIN) seed[u] = a.seeds[blk];
+    }
+    if constexpr (B >= 0 && MODE != MODE_PLAIN) {
+      // the seeds of the wave's 2 * U consecutive blocks: one coalesced load, handed out through scalar registers
+      hand_out<U>(a.seeds[tile * per_iter + (size_t)wv * 2 * U + (size_t)(lane % (2 * U))], h, seed);
     }
     if constexpr (B < 0) {
-      // widths and offsets are fetched side by side (two independent loads), the
-      // payload address then depends on both: two memory latencies, not three
+      // width, offset and seed of the wave's 2 * U consecutive blocks: one coalesced load per array, side by side
+      // (12 memory instructions fewer per wave than per-lane loads: 9 points of HBM peak).  The payload address
+      // depends on them: two memory latencies, not three
       uint64_t o[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) o[u] = a.off[first + 2 * (size_t)u];
+      constexpr int NB = 2 * U;
+      const size_t mine = tile * per_iter + (size_t)wv * NB + (size_t)(lane % NB);
+      const uint32_t mb = a.bits[mine];
+      const uint64_t mo = a.off[mine];
+      uint32_t ms = 0;
+      if constexpr (MODE != MODE_PLAIN) ms = a.seeds[mine];
+      hand_out<U>(mb, h, b);
+      hand_out<U>(mo, h, o);
+      if constexpr (MODE != MODE_PLAIN) hand_out<U>(ms, h, seed);
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const size_t blk = first + 2 * (size_t)u;
@@ -499,7 +508,7 @@ __global__ __launch_bounds__(BS) void k_unpack_fast(UnpackArgs a, uint32_t nwg =
     }
     if constexpr (B != 0) {
 #pragma unroll
-      for (int u = 0; u < U; ++u) ld[u] = *src[u];
+      for (int u = 0; u < U; ++u) ld[u] = load_global_at(reinterpret_cast<uintptr_t>(src[u]));
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -530,7 +539,14 @@ __global__ __launch_bounds__(BS) void k_pack_fast(PackArgs a) {
       if constexpr (B >= 0) {
         b[u] = B;
         pbase[u] = reinterpret_cast<uint8_t *>(payload + blk * (size_t)B);
-      } else {
+      }
+    }
+    // Per-block metadata, every lane loading its own block's entry: the encoders are bound by vector-ALU work, and
+    // handing coalesced loads out through scalar registers (as the decoders do) costs them 3-6 points of HBM peak.
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t blk = first + 2 * (size_t)u;
+      if constexpr (B < 0) {
         b[u] = a.bits[blk];
         pbase[u] = static_cast<uint8_t *>(a.payload) + a.off[blk] + (a.stream_layout ? a.chain_base + blk + 1 : 0);
       }
@@ -641,28 +657,37 @@ __global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
     u32x4 x[U];
     uint32_t seed[U];
     bool valid[U];
+    uint32_t out_bits = 0, out_seed = 0;
     // every load is issued unconditionally (a block past the end re-reads the last one; only the stores are
-    // predicated): behind a branch the loads of the U steps would wait for one another
+    // predicated), and the U loads of a kind back to back: behind a per-step branch they would wait for one another
+    size_t bc[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const size_t blk = first + 2 * (size_t)u;
       valid[u] = blk < a.nblocks;
-      const size_t bc = valid[u] ? blk : a.nblocks - 1;
+      bc[u] = valid[u] ? blk : a.nblocks - 1;
       seed[u] = a.seed0;
-      if (WHAT == RED_MAXBITS && a.group > 1) {
-        x[u] = u32x4{0, 0, 0, 0};
-        for (uint32_t g = 0; g < a.group; ++g) x[u] |= *reinterpret_cast<const u32x4 *>(a.in + (bc * a.group + g) * 128 + 4 * k);
-      } else {
-        x[u] = stream_load(reinterpret_cast<const u32x4 *>(a.in + bc * 128 + 4 * k));
+    }
+    if (WHAT == RED_MAXBITS && a.group > 1) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) x[u] = u32x4{0, 0, 0, 0};
+      for (uint32_t g = 0; g < a.group; ++g) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) x[u] |= *reinterpret_cast<const u32x4 *>(a.in + (bc[u] * a.group + g) * 128 + 4 * k);
       }
-      if constexpr (WHAT == RED_MAXBITSD1) {
-        // explicit offsets, or chained from the input: block k starts from in[128k-1], block 0 from seed0.  Chained,
-        // only the wave's first block reads it from memory: the others find it in the wave (below)
-        if (a.seeds || u == 0) {
-          const uint32_t *sp = a.seeds ? a.seeds + bc : a.in + (bc ? bc * 128 - 1 : 0);
-          const uint32_t s0 = *sp;
-          seed[u] = (a.seeds || bc) ? s0 : a.seed0;
-        }
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; ++u) x[u] = stream_load(reinterpret_cast<const u32x4 *>(a.in + bc[u] * 128 + 4 * k));
+    }
+    if constexpr (WHAT == RED_MAXBITSD1) {
+      // explicit offsets, or chained from the input: block k starts from in[128k-1], block 0 from seed0.  Chained,
+      // only the wave's first block reads it from memory: the others find it in the wave (below)
+      if (a.seeds) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) seed[u] = a.seeds[bc[u]];
+      } else {
+        const uint32_t s0 = a.in[bc[0] ? bc[0] * 128 - 1 : 0];
+        seed[0] = bc[0] ? s0 : a.seed0;
       }
     }
     if constexpr (WHAT == RED_MAXBITSD1) {
@@ -708,8 +733,22 @@ __global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
         t |= dpp0<DPP_ROW_SHR4>(t);
         t |= dpp0<DPP_ROW_SHR8>(t);
         t |= dpp0<DPP_ROW_BCAST15, 0xA>(t);
-        if (valid[u] && k == 31) a.bits_out[blk] = (uint8_t)bits_of(t);
-        if (WHAT == RED_MAXBITSD1 && a.seeds_out && valid[u] && k == 0) a.seeds_out[blk] = seed[u];
+        // results gathered into lanes 0 .. 2U-1 (block 2u + h of the wave in lane 2u + h): one store per array
+        const uint32_t w0 = bits_of((uint32_t)__builtin_amdgcn_readlane((int)t, 31));
+        const uint32_t w1 = bits_of((uint32_t)__builtin_amdgcn_readlane((int)t, 63));
+        out_bits = lane == 2 * u ? w0 : (lane == 2 * u + 1 ? w1 : out_bits);
+        if constexpr (WHAT == RED_MAXBITSD1) {
+          const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)seed[u], 0);
+          const uint32_t s1 = (uint32_t)__builtin_amdgcn_readlane((int)seed[u], 32);
+          out_seed = lane == 2 * u ? s0 : (lane == 2 * u + 1 ? s1 : out_seed);
+        }
+      }
+    }
+    if constexpr (WHAT != RED_MINMAX) {
+      const size_t mine = tile * per_iter + (size_t)wv * 2 * U + (size_t)lane;
+      if (lane < 2 * U && mine < a.nblocks) {
+        a.bits_out[mine] = (uint8_t)out_bits;
+        if (WHAT == RED_MAXBITSD1 && a.seeds_out) a.seeds_out[mine] = out_seed;
       }
     }
   }

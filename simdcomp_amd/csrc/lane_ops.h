@@ -10,6 +10,41 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // The same 16 bytes at any byte address: global memory runs in unaligned mode on this platform, so this is still one
 // global_load_dwordx4 / global_store_dwordx4 (tools/exp/unaligned_exp.hip checks it).  LDS accesses stay aligned.
 typedef u32x4 u32x4_u __attribute__((aligned(1)));
+// A wave works on 2 * U consecutive blocks: block 2u + h belongs to half-wave h at step u.  Per-block metadata is
+// fetched with ONE coalesced load per array (lane l holds the entry of block l mod 2U) and handed to its half-wave
+// through scalar registers: 2U / 1 fewer memory instructions than every lane loading its own block's entry.
+template <int U>
+__device__ __forceinline__ void hand_out(uint32_t mine, int h, uint32_t (&v)[U]) {
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const uint32_t v0 = (uint32_t)__builtin_amdgcn_readlane((int)mine, 2 * u);
+    const uint32_t v1 = (uint32_t)__builtin_amdgcn_readlane((int)mine, 2 * u + 1);
+    v[u] = h ? v1 : v0;
+  }
+}
+template <int U>
+__device__ __forceinline__ void hand_out(uint64_t mine, int h, uint64_t (&v)[U]) {
+  uint32_t lo[U], hi[U];
+  hand_out<U>((uint32_t)mine, h, lo);
+  hand_out<U>((uint32_t)(mine >> 32), h, hi);
+#pragma unroll
+  for (int u = 0; u < U; ++u) v[u] = ((uint64_t)hi[u] << 32) | lo[u];
+}
+
+// 16 readable bytes for loads that have nothing to read: an optional array that is absent, a zero-width block.  The
+// load is issued all the same, so that it sits next to its neighbours instead of behind a branch of its own (after a
+// branch the compiler waits for everything in flight before the next load goes out).
+static __device__ u32x4 g_nothing;
+
+// A load from an address that went through integer arithmetic: the cast back names the global address space, so the
+// compiler emits a global load (a generic pointer gives a flat load, which also counts against the LDS wait counter).
+template <typename T>
+__device__ __forceinline__ T load_global_as(uintptr_t at) {
+  return *(const __attribute__((address_space(1))) T *)at;
+}
+__device__ __forceinline__ u32x4 load_global_at(uintptr_t at) {
+  return *(const __attribute__((address_space(1))) u32x4_u *)at;
+}
 
 constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118;
 constexpr int DPP_ROW_BCAST15 = 0x142;

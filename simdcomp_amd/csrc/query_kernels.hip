@@ -40,34 +40,51 @@ __global__ __launch_bounds__(256) void k_query(QueryArgs a) {
   const uint32_t *vals = reinterpret_cast<const uint32_t *>(vals4);
   const size_t first = ((size_t)blockIdx.x * 4 + wv) * 2 * U + h;
   size_t qcs[U], blks[U];
-  uint32_t bs[U], seeds[U];
+  uint32_t bs[U], seeds[U], keys_or_slots[U];
+  int lens[U];
   const uint8_t *pbases[U];
   u32x4 lds_in[U];
+  // Three rounds of loads, each round's loads side by side: (block id, key or slot, length) -> (width, offset,
+  // seed) -> payload.  Optional arrays that are absent are "read" from g_nothing, so that no load hides behind a
+  // branch of its own.
+  const uintptr_t nothing = reinterpret_cast<uintptr_t>(&g_nothing);
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const size_t q = first + 2 * (size_t)u;
     qcs[u] = q < a.nqueries ? q : a.nqueries - 1;
-    blks[u] = a.query_blocks ? a.query_blocks[qcs[u]] : qcs[u];
+    const uint64_t qb = load_global_as<uint64_t>(a.query_blocks ? reinterpret_cast<uintptr_t>(a.query_blocks + qcs[u]) : nothing);
+    blks[u] = a.query_blocks ? (size_t)qb : qcs[u];
+    const void *ks = WHAT == Q_SELECT ? static_cast<const void *>(a.slots) : static_cast<const void *>(a.keys);
+    keys_or_slots[u] = load_global_as<uint32_t>(WHAT != Q_SCAN ? reinterpret_cast<uintptr_t>(ks) + 4 * qcs[u] : nothing);
+    const int ln = load_global_as<int>(WHAT == Q_SEARCH && a.lengths ? reinterpret_cast<uintptr_t>(a.lengths + qcs[u]) : nothing);
+    lens[u] = a.lengths ? ln : 128;
   }
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    bs[u] = a.bits ? a.bits[blks[u]] : a.bit;
-    pbases[u] = static_cast<const uint8_t *>(a.payload);
-    if (a.off) pbases[u] += a.off[blks[u]] + (a.stream_layout ? blks[u] + 1 : 0);
-    seeds[u] = MODE == MODE_PLAIN ? 0u : (a.seeds ? a.seeds[blks[u]] : a.seed0);
-  }
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
+    const uint8_t wb = load_global_as<uint8_t>(a.bits ? reinterpret_cast<uintptr_t>(a.bits + blks[u]) : nothing);
+    const uint64_t po = load_global_as<uint64_t>(a.off ? reinterpret_cast<uintptr_t>(a.off + blks[u]) : nothing);
+    const uint32_t sd = load_global_as<uint32_t>(MODE != MODE_PLAIN && a.seeds ? reinterpret_cast<uintptr_t>(a.seeds + blks[u]) : nothing);
+    bs[u] = a.bits ? wb : a.bit;
     bs[u] = bs[u] > 32 ? 32 : bs[u];
-    if (!a.off) pbases[u] += blks[u] * 16 * (size_t)bs[u];
-    lds_in[u] = u32x4{0, 0, 0, 0};
-    if ((uint32_t)k < bs[u]) lds_in[u] = *reinterpret_cast<const u32x4_u *>(pbases[u] + 16 * k);
+    pbases[u] = static_cast<const uint8_t *>(a.payload);
+    // both terms are always computed (masks instead of a choice): a choice would put the offset load behind a branch
+    // that waits for the width
+    const uint64_t has_off = a.off ? ~0ull : 0ull;
+    pbases[u] += (po & has_off) + ((a.stream_layout ? blks[u] + 1 : 0) & has_off) + ((blks[u] * 16 * (size_t)bs[u]) & ~has_off);
+    seeds[u] = MODE == MODE_PLAIN ? 0u : (a.seeds ? sd : a.seed0);
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    // every lane loads (lanes past the payload's end re-read its last vector, a zero-width block reads g_nothing):
+    // a predicated load would pull the offset load above under the same predicate, behind the wait for the width
+    const uint32_t last = bs[u] ? bs[u] - 1 : 0;
+    const uintptr_t at = reinterpret_cast<uintptr_t>(pbases[u]) + 16 * ((uint32_t)k < last ? (uint32_t)k : last);
+    lds_in[u] = load_global_at(bs[u] ? at : nothing);
   }
 #pragma unroll
   for (int u = 0; u < U; ++u) {
   const size_t q = first + 2 * (size_t)u;
   const bool valid = q < a.nqueries;
-  const size_t qc = qcs[u];
   const uint32_t b = bs[u];
   const uint32_t seed = seeds[u];
   wave_lds_fence();
@@ -97,13 +114,13 @@ __global__ __launch_bounds__(256) void k_query(QueryArgs a) {
   wave_lds_fence();
 
   if constexpr (WHAT == Q_SELECT) {
-    const uint32_t at = (uint32_t)a.slots[qc] & 127u;
+    const uint32_t at = keys_or_slots[u] & 127u;
     if (valid && k == 0) a.values_out[q] = vals[at];
   } else if constexpr (WHAT == Q_SCAN) {
     if (valid && k == 31) *reinterpret_cast<u32x4_u *>(a.last4_out + 4 * q) = v;
   } else {
-    const uint32_t key = a.keys[qc];
-    int length = a.lengths ? a.lengths[qc] : 128;
+    const uint32_t key = keys_or_slots[u];
+    int length = lens[u];
     length = length < 0 ? 0 : (length > 128 ? 128 : length);
     int pos;
     uint32_t value;

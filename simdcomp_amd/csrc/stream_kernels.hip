@@ -39,16 +39,19 @@ __global__ __launch_bounds__(256) void k_block_sums(const uint8_t *payload, cons
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int h = lane >> 5, k = lane & 31;
   u32x4 *slot = lds[wv][h];
-  const size_t first = ((size_t)blockIdx.x * 4 + wv) * 2 * U + h;
   uint32_t b[U];
   uint64_t o[U];
   u32x4 ld[U];
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const size_t blk = first + 2 * (size_t)u;
-    const size_t bc = blk < nblocks ? blk : nblocks - 1;
-    b[u] = bits[bc];
-    o[u] = off[bc] + (stream_layout ? bc + 1 : 0);
+  // widths and offsets of the wave's 2 * U consecutive blocks: one coalesced load per array, handed to the half-waves
+  // through scalar registers (blocks past the end repeat the last one)
+  constexpr int NB = 2 * U;
+  const size_t wb = ((size_t)blockIdx.x * 4 + wv) * NB;
+  {
+    const size_t mine = wb + (size_t)(lane % NB) < nblocks ? wb + (size_t)(lane % NB) : nblocks - 1;
+    const uint32_t mb = bits[mine];
+    const uint64_t mo = off[mine] + (stream_layout ? mine + 1 : 0);
+    hand_out<U>(mb, h, b);
+    hand_out<U>(mo, h, o);
   }
 #pragma unroll
   for (int u = 0; u < U; ++u) {
@@ -56,11 +59,11 @@ __global__ __launch_bounds__(256) void k_block_sums(const uint8_t *payload, cons
     const uint32_t last = b[u] ? b[u] - 1 : 0;
     uintptr_t at = reinterpret_cast<uintptr_t>(payload) + o[u] + 16 * ((uint32_t)k < last ? (uint32_t)k : last);
     at = (uint32_t)k > last ? (at & ~(uintptr_t)15) : at;  // idle lanes: an aligned address coalesces better
-    ld[u] = *(b[u] ? reinterpret_cast<const u32x4_u *>(at) : reinterpret_cast<const u32x4_u *>(sums));
+    ld[u] = load_global_at(b[u] ? at : reinterpret_cast<uintptr_t>(sums));
   }
+  uint32_t mine_out = 0;
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    const size_t blk = first + 2 * (size_t)u;
     wave_lds_fence();
     slot[k] = ld[u];
     wave_lds_fence();
@@ -73,8 +76,12 @@ __global__ __launch_bounds__(256) void k_block_sums(const uint8_t *payload, cons
     v.z = funnel(hi.z, lo.z, s) & m;
     v.w = funnel(hi.w, lo.w, s) & m;
     const uint32_t total = half_scan_add(v.x + v.y + v.z + v.w);  // lane 31 of the half-wave: the block's sum
-    if (blk < nblocks && k == 31) sums[blk] = b[u] == 32 ? v.w : total;
+    const uint32_t res = b[u] == 32 ? v.w : total;
+    // gathered into lanes 0 .. 2U-1 for one coalesced store
+    const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)res, 31), r1 = (uint32_t)__builtin_amdgcn_readlane((int)res, 63);
+    mine_out = lane == 2 * u ? r0 : (lane == 2 * u + 1 ? r1 : mine_out);
   }
+  if (lane < NB && wb + (size_t)lane < nblocks) sums[wb + (size_t)lane] = mine_out;
 }
 
 // (restart flag << 32) | value
@@ -183,12 +190,12 @@ __global__ __launch_bounds__(256) void k_stream_copy(const uint8_t *src, uint8_t
   uint32_t b[U];
   uint64_t o[U];
   u32x4 x[U];
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const size_t blk = first + 2 * (size_t)u;
-    const size_t bc = blk < nblocks ? blk : nblocks - 1;
-    b[u] = bits[bc];
-    o[u] = off[bc];
+  {
+    // one coalesced load per array for the wave's 2 * U consecutive blocks (blocks past the end repeat the last one)
+    const size_t wb = ((size_t)blockIdx.x * 4 + wv) * 2 * U + (size_t)(lane % (2 * U));
+    const size_t mine = wb < nblocks ? wb : nblocks - 1;
+    hand_out<U>((uint32_t)bits[mine], h, b);
+    hand_out<U>(off[mine], h, o);
   }
 #pragma unroll
   for (int u = 0; u < U; ++u) {
@@ -197,9 +204,11 @@ __global__ __launch_bounds__(256) void k_stream_copy(const uint8_t *src, uint8_t
     b[u] = b[u] > 32 ? 32 : b[u];
     const uint32_t last = b[u] ? b[u] - 1 : 0;
     const uint64_t from = o[u] + (TO_STREAM ? 0 : bc + 1) + 16 * ((uint32_t)k < last ? (uint32_t)k : last);
-    // a zero-width block has nothing to read
-    x[u] = u32x4{0, 0, 0, 0};
-    if (b[u]) x[u] = *reinterpret_cast<const u32x4_u *>(src + from);
+    // a zero-width block has nothing to read, but its load is issued all the same (from 16 bytes that are always
+    // there): behind a branch each of the U loads would wait for the one before
+    uintptr_t at = reinterpret_cast<uintptr_t>(src + from);
+    at = (uint32_t)k > last ? (at & ~(uintptr_t)15) : at;  // idle lanes: an aligned address coalesces better
+    x[u] = load_global_at(b[u] ? at : reinterpret_cast<uintptr_t>(&g_nothing));
   }
 #pragma unroll
   for (int u = 0; u < U; ++u) {
