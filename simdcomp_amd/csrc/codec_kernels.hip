@@ -769,12 +769,27 @@ __device__ __forceinline__ uint64_t block_reduce_sum(uint64_t v, uint64_t *sh) {
   return tot;
 }
 
+// A tile is 4096 widths: wave w takes 1024 consecutive ones in 16 rounds of 64, lane l the width at 64 * round + l, so
+// that every load and store is one coalesced instruction and all 16 loads go out back to back (widths past the end
+// re-read the last one and count as zero).
+__device__ __forceinline__ void scan_load_widths(const uint8_t *bits, size_t n, size_t wave_base, int lane, uint32_t (&v)[16]) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const size_t i = wave_base + 64 * (size_t)r + (size_t)lane;
+    v[r] = bits[i < n ? i : n - 1];
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] = wave_base + 64 * (size_t)r + (size_t)lane < n ? v[r] : 0u;
+}
+
 __global__ __launch_bounds__(256) void k_scan_tile_sums(const uint8_t *bits, size_t n, uint64_t *tile_sums) {
   __shared__ uint64_t sh[4];
-  const size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * 16;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  uint32_t v[16];
+  scan_load_widths(bits, n, (size_t)blockIdx.x * SCAN_TILE + (size_t)wv * 1024, lane, v);
   uint64_t s = 0;
-  for (int i = 0; i < 16; ++i)
-    if (base + i < n) s += bits[base + i];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s += v[r];
   const uint64_t tot = block_reduce_sum(s, sh);
   if (threadIdx.x == 0) tile_sums[blockIdx.x] = tot * 16;
 }
@@ -803,26 +818,37 @@ __global__ __launch_bounds__(256) void k_scan_spine(uint64_t *tile_sums, size_t 
 
 __global__ __launch_bounds__(256) void k_scan_apply(const uint8_t *bits, size_t n, const uint64_t *tile_sums,
                                                     uint64_t *off) {
-  __shared__ uint64_t sh[256];
-  const size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * 16;
-  uint32_t loc[16];
-  uint64_t s = 0;
-  for (int i = 0; i < 16; ++i) {
-    loc[i] = base + i < n ? bits[base + i] : 0;
-    s += loc[i];
+  __shared__ uint64_t sh[4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const size_t wave_base = (size_t)blockIdx.x * SCAN_TILE + (size_t)wv * 1024;
+  uint32_t v[16];
+  scan_load_widths(bits, n, wave_base, lane, v);
+  const uint64_t tile_in = tile_sums[blockIdx.x];
+  // inclusive scans of the 16 rounds (sums of 64 widths fit 32 bits), then the rounds chained through lane 63
+  uint32_t inc[16];
+  uint64_t before[16];
+  uint64_t run = 0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    uint32_t t = v[r];
+    t += dpp0<DPP_ROW_SHR1>(t);
+    t += dpp0<DPP_ROW_SHR2>(t);
+    t += dpp0<DPP_ROW_SHR4>(t);
+    t += dpp0<DPP_ROW_SHR8>(t);
+    t += dpp0<DPP_ROW_BCAST15, 0xA>(t);
+    t += dpp0<DPP_ROW_BCAST31, 0xC>(t);
+    inc[r] = t;
+    before[r] = run;
+    run += (uint32_t)__builtin_amdgcn_readlane((int)t, 63);
   }
-  sh[threadIdx.x] = s;
+  if (lane == 0) sh[wv] = run;
   __syncthreads();
-  for (int d = 1; d < 256; d <<= 1) {
-    const uint64_t t = threadIdx.x >= (unsigned)d ? sh[threadIdx.x - d] : 0;
-    __syncthreads();
-    sh[threadIdx.x] += t;
-    __syncthreads();
-  }
-  uint64_t run = tile_sums[blockIdx.x] + (sh[threadIdx.x] - s) * 16;
-  for (int i = 0; i < 16; ++i) {
-    if (base + i < n) off[base + i] = run;
-    run += (uint64_t)loc[i] * 16;
+  uint64_t waves_before = 0;
+  for (int w = 0; w < wv; ++w) waves_before += sh[w];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const size_t i = wave_base + 64 * (size_t)r + (size_t)lane;
+    if (i < n) off[i] = tile_in + 16 * (waves_before + before[r] + inc[r] - v[r]);
   }
 }
 

@@ -48,6 +48,7 @@ __device__ __forceinline__ u32x4 load_global_at(uintptr_t at) {
 
 constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118;
 constexpr int DPP_ROW_BCAST15 = 0x142;
+constexpr int DPP_ROW_BCAST31 = 0x143;
 constexpr int DPP_WAVE_SHR1 = 0x138;
 
 // Lane l receives `v` from the lane the DPP control names, or 0 where that lane
@@ -105,6 +106,18 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Inclusive scan over the 64 lanes of a wave under an associative (not necessarily commutative) operator:
+// lane i ends with op(v[0], ..., v[i]) in lane order.
+template <typename Op>
+__device__ __forceinline__ uint64_t wave_scan_incl(uint64_t v, int lane, Op op) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint64_t t = __shfl_up((unsigned long long)v, d, 64);
+    if (lane >= d) v = op(t, v);
+  }
+  return v;
 }
 
 __device__ __forceinline__ uint32_t bits_of(uint32_t v) { return v ? 32u - (uint32_t)__builtin_clz(v) : 0u; }

@@ -106,14 +106,45 @@ __device__ __forceinline__ void chain_wg_scan(uint64_t v, uint64_t *sh) {
   }
 }
 
+// A tile is CHAIN_TILE blocks: wave w takes 1024 consecutive ones in 16 rounds of 64, lane l the block at
+// 64 * round + l: every load and store is one coalesced instruction, and the 32 loads go out back to back (blocks past
+// the end re-read the last one and count as the identity).
+__device__ __forceinline__ void chain_load(const uint8_t *bits, const uint32_t *sums, size_t n, size_t wave_base, int lane,
+                                           uint64_t (&el)[16]) {
+  uint32_t w[16], sm[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const size_t i = wave_base + 64 * (size_t)r + (size_t)lane;
+    const size_t ic = i < n ? i : n - 1;
+    w[r] = bits[ic];
+    sm[r] = sums[ic];
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) el[r] = wave_base + 64 * (size_t)r + (size_t)lane < n ? chain_element(w[r], sm[r]) : 0;
+}
+
+// Scans the wave's 16 rounds in place (el[r] becomes the inclusive scan within the round) and returns what the wave's
+// 1024 blocks compose to; before[r] is what the rounds in front of round r compose to.
+__device__ __forceinline__ uint64_t chain_wave_scan(uint64_t (&el)[16], uint64_t (&before)[16], int lane) {
+  uint64_t run = 0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    el[r] = wave_scan_incl(el[r], lane, chain_compose);
+    before[r] = run;
+    run = chain_compose(run, __shfl((unsigned long long)el[r], 63, 64));
+  }
+  return run;
+}
+
 __global__ __launch_bounds__(256) void k_chain_tiles(const uint8_t *bits, const uint32_t *sums, size_t n, uint64_t *tile_sum) {
-  __shared__ uint64_t sh[256];
-  const size_t base = (size_t)blockIdx.x * CHAIN_TILE + (size_t)threadIdx.x * 16;
-  uint64_t e = 0;
-  for (int i = 0; i < 16; ++i)
-    if (base + i < n) e = chain_compose(e, chain_element(bits[base + i], sums[base + i]));
-  chain_wg_scan(e, sh);
-  if (threadIdx.x == 255) tile_sum[blockIdx.x] = sh[255];
+  __shared__ uint64_t sh[4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  uint64_t el[16], before[16];
+  chain_load(bits, sums, n, (size_t)blockIdx.x * CHAIN_TILE + (size_t)wv * 1024, lane, el);
+  const uint64_t total = chain_wave_scan(el, before, lane);
+  if (lane == 0) sh[wv] = total;
+  __syncthreads();
+  if (threadIdx.x == 0) tile_sum[blockIdx.x] = chain_compose(chain_compose(sh[0], sh[1]), chain_compose(sh[2], sh[3]));
 }
 
 // one workgroup: tile_in[t] = offset entering tile t
@@ -132,19 +163,24 @@ __global__ __launch_bounds__(256) void k_chain_spine(const uint64_t *tile_sum, s
 
 __global__ __launch_bounds__(256) void k_chain_apply(const uint8_t *bits, const uint32_t *sums, size_t n, const uint32_t *tile_in,
                                                      uint32_t *seeds) {
-  __shared__ uint64_t sh[256];
-  const size_t base = (size_t)blockIdx.x * CHAIN_TILE + (size_t)threadIdx.x * 16;
-  uint64_t el[16];
-  uint64_t e = 0;
-  for (int i = 0; i < 16; ++i) {
-    el[i] = base + i < n ? chain_element(bits[base + i], sums[base + i]) : 0;
-    e = chain_compose(e, el[i]);
-  }
-  chain_wg_scan(e, sh);
-  uint64_t state = chain_compose((1ull << 32) | tile_in[blockIdx.x], threadIdx.x ? sh[threadIdx.x - 1] : 0);
-  for (int i = 0; i < 16; ++i) {
-    if (base + i < n) seeds[base + i] = (uint32_t)state;
-    state = chain_compose(state, el[i]);
+  __shared__ uint64_t sh[4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const size_t wave_base = (size_t)blockIdx.x * CHAIN_TILE + (size_t)wv * 1024;
+  uint64_t el[16], before[16];
+  chain_load(bits, sums, n, wave_base, lane, el);
+  const uint64_t entering = (1ull << 32) | tile_in[blockIdx.x];
+  const uint64_t total = chain_wave_scan(el, before, lane);
+  if (lane == 0) sh[wv] = total;
+  __syncthreads();
+  uint64_t state = entering;
+  for (int w = 0; w < wv; ++w) state = chain_compose(state, sh[w]);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    // the offset of a block: everything in front of it, i.e. the inclusive scan of the lane before
+    const uint64_t prev = __shfl_up((unsigned long long)el[r], 1, 64);
+    const uint64_t in_round = lane ? prev : 0;
+    const size_t i = wave_base + 64 * (size_t)r + (size_t)lane;
+    if (i < n) seeds[i] = (uint32_t)chain_compose(chain_compose(state, before[r]), in_round);
   }
 }
 
