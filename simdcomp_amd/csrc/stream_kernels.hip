@@ -281,9 +281,12 @@ hipError_t launch_stream_unbuild(const uint8_t *stream, const uint64_t *off, con
 // bytes.  The first record of a chunk starts at one of 513 places (a record is at most 513 bytes long), so
 //   A  every chunk walks the chain from all 513 candidate entries at once (chunk staged in LDS) and tabulates, per
 //      candidate, where the walk leaves the chunk (0..512 bytes into the next one) and how many records it saw;
-//   B  groups of IDX_GROUP chunks compose their tables (thread f follows candidate f through the group);
-//   C  one thread walks the group tables from the known entry of the stream (byte 0) and fixes every group's entry
-//      and first record number;  D  one thread per group does the same for its chunks;
+//   B  groups of IDX_GROUP chunks compose their tables (thread f follows candidate f through the group), and
+//      super-groups of IDX_SUPER groups compose the group tables the same way: a chain of 32 dependent loads each,
+//      instead of one long chain;
+//   C  one thread walks the super-group tables from the known entry of the stream (byte 0) and fixes every
+//      super-group's entry and first record number;  D  one thread per super-group does the same for its groups,
+//      then one thread per group for its chunks;
 //   E  every chunk walks its true chain once more and writes width and arena offset of each record.
 // A width byte above 32 ends a walk as invalid; the true chain hitting one is reported in result[2].
 #ifndef SC_IDX_CHUNK
@@ -292,7 +295,8 @@ hipError_t launch_stream_unbuild(const uint8_t *stream, const uint64_t *off, con
 constexpr int IDX_CHUNK = SC_IDX_CHUNK;
 constexpr int IDX_CAND = 513;
 constexpr int IDX_THREADS = 256;
-constexpr int IDX_GROUP = 256;
+constexpr int IDX_GROUP = 32;  // chunks per group
+constexpr int IDX_SUPER = 32;  // groups per super-group
 constexpr uint32_t IDX_INVALID = 0xFFFFFFFFu;
 constexpr uint64_t IDX_INVALID64 = ~0ull;
 
@@ -423,6 +427,51 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_index_groups(const uint32_t *
   gtable[(size_t)blockIdx.x * IDX_CAND + threadIdx.x] = bad ? IDX_INVALID64 : ((cnt << 16) | state);
 }
 
+// Tables of IDX_SUPER consecutive groups composed into one (same walk as above over 64-bit entries).
+__global__ __launch_bounds__(GROUP_THREADS) void k_index_supers(const uint64_t *gtable, size_t ngroups, uint64_t *stable) {
+  if (threadIdx.x >= IDX_CAND) return;
+  const size_t gbeg = (size_t)blockIdx.x * IDX_SUPER;
+  const size_t gend = gbeg + IDX_SUPER < ngroups ? gbeg + IDX_SUPER : ngroups;
+  uint64_t state = threadIdx.x, cnt = 0;
+  bool bad = false;
+  for (size_t g = gbeg; g < gend; ++g) {
+    const uint64_t e = gtable[g * IDX_CAND + state];
+    if (e == IDX_INVALID64) {
+      bad = true;
+      break;
+    }
+    cnt += e >> 16;
+    state = e & 0xFFFF;
+  }
+  stable[(size_t)blockIdx.x * IDX_CAND + threadIdx.x] = bad ? IDX_INVALID64 : ((cnt << 16) | state);
+}
+
+// One thread per super-group: entry (first record number << 16 | entry byte) of each of its groups.
+__global__ __launch_bounds__(64) void k_index_group_entries(const uint64_t *gtable, size_t ngroups, size_t nsupers,
+                                                            const uint64_t *sentry, uint64_t *gentry) {
+  const size_t sg = (size_t)blockIdx.x * 64 + threadIdx.x;
+  if (sg >= nsupers) return;
+  const size_t gbeg = sg * IDX_SUPER;
+  const size_t gend = gbeg + IDX_SUPER < ngroups ? gbeg + IDX_SUPER : ngroups;
+  const uint64_t se = sentry[sg];
+  bool bad = se == IDX_INVALID64;
+  uint64_t state = se & 0xFFFF, base = se >> 16;
+  for (size_t g = gbeg; g < gend; ++g) {
+    if (bad) {
+      gentry[g] = IDX_INVALID64;
+      continue;
+    }
+    gentry[g] = (base << 16) | state;
+    const uint64_t e = gtable[g * IDX_CAND + state];
+    if (e == IDX_INVALID64) {
+      bad = true;  // this group still hands entries to the chunks in front of the bad byte
+      continue;
+    }
+    base += e >> 16;
+    state = e & 0xFFFF;
+  }
+}
+
 __global__ void k_index_spine(const uint64_t *gtable, size_t ngroups, size_t nbytes, uint64_t *gentry, uint64_t *result) {
   uint64_t state = 0, base = 0;
   bool bad = false;
@@ -529,26 +578,37 @@ hipError_t launch_stream_bytes(const uint64_t *payload_bytes, size_t nblocks, ui
 
 static size_t idx_chunks(size_t nbytes) { return (nbytes + IDX_CHUNK - 1) / IDX_CHUNK; }
 
+static size_t idx_groups(size_t nchunks) { return (nchunks + IDX_GROUP - 1) / IDX_GROUP; }
+static size_t idx_supers(size_t ngroups) { return (ngroups + IDX_SUPER - 1) / IDX_SUPER; }
+
 size_t stream_index_workspace_bytes(size_t nbytes) {
-  const size_t nchunks = idx_chunks(nbytes), ngroups = (nchunks + IDX_GROUP - 1) / IDX_GROUP;
-  return align256(4 * IDX_CAND * nchunks) + align256(8 * IDX_CAND * ngroups) + align256(8 * ngroups) + align256(8 * nchunks) + 256;
+  const size_t nchunks = idx_chunks(nbytes), ngroups = idx_groups(nchunks), nsupers = idx_supers(ngroups);
+  return align256(4 * IDX_CAND * nchunks) + align256(8 * IDX_CAND * ngroups) + align256(8 * IDX_CAND * nsupers) +
+         align256(8 * nsupers) + align256(8 * ngroups) + align256(8 * nchunks) + 256;
 }
 
 hipError_t launch_stream_index(const uint8_t *stream, size_t nbytes, size_t max_blocks, uint8_t *bits, uint64_t *off,
                                uint64_t *result, void *workspace, hipStream_t st) {
   if (nbytes == 0) return hipMemsetAsync(result, 0, 3 * sizeof(uint64_t), st);
-  const size_t nchunks = idx_chunks(nbytes), ngroups = (nchunks + IDX_GROUP - 1) / IDX_GROUP;
+  const size_t nchunks = idx_chunks(nbytes), ngroups = idx_groups(nchunks), nsupers = idx_supers(ngroups);
   uint8_t *ws = static_cast<uint8_t *>(workspace);
   uint32_t *table = reinterpret_cast<uint32_t *>(ws);
   ws += align256(4 * IDX_CAND * nchunks);
   uint64_t *gtable = reinterpret_cast<uint64_t *>(ws);
   ws += align256(8 * IDX_CAND * ngroups);
+  uint64_t *stable = reinterpret_cast<uint64_t *>(ws);
+  ws += align256(8 * IDX_CAND * nsupers);
+  uint64_t *sentry = reinterpret_cast<uint64_t *>(ws);
+  ws += align256(8 * nsupers);
   uint64_t *gentry = reinterpret_cast<uint64_t *>(ws);
   ws += align256(8 * ngroups);
   uint64_t *centry = reinterpret_cast<uint64_t *>(ws);
   hipLaunchKernelGGL(k_index_candidates, dim3((unsigned)nchunks), dim3(IDX_THREADS), 0, st, stream, nbytes, table);
   hipLaunchKernelGGL(k_index_groups, dim3((unsigned)ngroups), dim3(GROUP_THREADS), 0, st, table, nchunks, gtable);
-  hipLaunchKernelGGL(k_index_spine, dim3(1), dim3(1), 0, st, gtable, ngroups, nbytes, gentry, result);
+  hipLaunchKernelGGL(k_index_supers, dim3((unsigned)nsupers), dim3(GROUP_THREADS), 0, st, gtable, ngroups, stable);
+  hipLaunchKernelGGL(k_index_spine, dim3(1), dim3(1), 0, st, stable, nsupers, nbytes, sentry, result);
+  hipLaunchKernelGGL(k_index_group_entries, dim3((unsigned)((nsupers + 63) / 64)), dim3(64), 0, st, gtable, ngroups, nsupers,
+                     sentry, gentry);
   hipLaunchKernelGGL(k_index_chunk_entries, dim3((unsigned)((ngroups + 63) / 64)), dim3(64), 0, st, table, nchunks, ngroups, gentry,
                      centry);
   hipLaunchKernelGGL(k_index_emit, dim3((unsigned)((nchunks + EMIT_THREADS - 1) / EMIT_THREADS)), dim3(EMIT_THREADS), 0, st, stream,
