@@ -28,7 +28,7 @@ namespace sc {
 // up front to have enough bytes in flight.  Lanes past a payload's end re-read
 // its last vector; a zero-width block reads the first 16 bytes of `sums`.
 #ifndef SC_SUMS_U
-#define SC_SUMS_U 4
+#define SC_SUMS_U 8
 #endif
 constexpr int SUMS_U = SC_SUMS_U;
 
