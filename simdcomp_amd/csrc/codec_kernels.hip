@@ -55,9 +55,12 @@ __global__ __launch_bounds__(256) void k_unpack_flex(UnpackArgs a) {
   const int h = lane >> 5, k = lane & 31;
   u32x4 *slot = lds[wv][h];
   const uint8_t *payload_bytes = static_cast<const uint8_t *>(a.payload);
-  const size_t S = a.lane_groups > 1 ? a.lane_groups : 1;  // 4-lane groups per wide block (see UnpackArgs)
+  // 4-lane groups per wide block (see UnpackArgs): 1, 2 or 4, as a shift
+  const uint32_t ls = a.lane_groups > 2 ? 2u : (a.lane_groups > 1 ? 1u : 0u);
+  const size_t S = (size_t)1 << ls;
   const size_t per_iter = (size_t)BLOCKS_PER_STEP * U;
   const size_t ntiles = (a.nblocks + per_iter - 1) / per_iter;
+  const uintptr_t nothing = reinterpret_cast<uintptr_t>(&g_nothing);
 
   for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const size_t first = tile * per_iter + (size_t)wv * 2 * U + h;
@@ -66,38 +69,38 @@ __global__ __launch_bounds__(256) void k_unpack_flex(UnpackArgs a) {
     uint32_t b[U], seed[U];
     const uint8_t *pbase[U];
     u32x4 ld[U];
+    // Every load is issued whatever the block (blocks past the end repeat the last one, absent arrays are "read"
+    // from g_nothing, rows past the payload's end re-read its last vector; only the stores are predicated): a load
+    // behind a branch of its own would wait for all the loads in front of it.
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       blk[u] = first + 2 * (size_t)u;
       valid[u] = blk[u] < a.nblocks;
+      const size_t bc = valid[u] ? blk[u] : a.nblocks - 1;
+      const uint32_t wb = load_global_as<uint8_t>(B < 0 && a.bits ? reinterpret_cast<uintptr_t>(a.bits + bc) : nothing);
+      const uint64_t po = load_global_as<uint64_t>(a.off ? reinterpret_cast<uintptr_t>(a.off + bc) : nothing);
+      const uint32_t sd = load_global_as<uint32_t>(MODE != MODE_PLAIN && a.seeds ? reinterpret_cast<uintptr_t>(a.seeds + bc) : nothing);
       if constexpr (B >= 0) {
         b[u] = B;
       } else {
-        b[u] = a.bits ? (valid[u] ? a.bits[blk[u]] : 0u) : a.bit;
+        b[u] = a.bits ? (valid[u] ? wb : 0u) : a.bit;
       }
+      const uint64_t has_off = a.off ? ~0ull : 0ull;
+      const uint64_t by_off = po + (a.stream_layout ? a.block_base + bc + 1 : 0);
+      const uint64_t uniform = (bc >> ls) * (16 * (size_t)b[u] * S) + 16 * (bc & (S - 1));
+      pbase[u] = payload_bytes + ((by_off & has_off) | (uniform & ~has_off));
+      if constexpr (MODE != MODE_PLAIN) seed[u] = a.seeds ? sd : a.seed0;
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      pbase[u] = payload_bytes;
-      if (a.off) {
-        if (valid[u]) pbase[u] += a.off[blk[u]] + (a.stream_layout ? a.block_base + blk[u] + 1 : 0);
-      } else {
-        pbase[u] += (blk[u] / S) * (16 * (size_t)b[u] * S) + 16 * (blk[u] % S);
-      }
-      if constexpr (MODE != MODE_PLAIN) {
-        seed[u] = a.seeds ? (valid[u] ? a.seeds[blk[u]] : 0u) : a.seed0;
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      ld[u] = u32x4{0, 0, 0, 0};
       uint32_t nvec = b[u];
       if constexpr (TAIL) {
         const size_t start = blk[u] * 128;
         const size_t nval = start < a.length ? (a.length - start < 128 ? a.length - start : 128) : 0;
         nvec = (uint32_t)((((nval + 3) / 4) * b[u] + 31) / 32);
       }
-      if (valid[u] && (uint32_t)k < nvec) ld[u] = *reinterpret_cast<const u32x4_u *>(pbase[u] + 16 * S * k);
+      const uint32_t row = (uint32_t)k < nvec ? (uint32_t)k : (nvec ? nvec - 1 : 0);
+      ld[u] = load_global_at(nvec ? reinterpret_cast<uintptr_t>(pbase[u] + 16 * S * row) : nothing);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(256) void k_unpack_flex(UnpackArgs a) {
         }
       }
       if (valid[u]) {
-        uint32_t *o = a.out + (blk[u] / S) * (128 * S) + 4 * S * k + 4 * (blk[u] % S);
+        uint32_t *o = a.out + (blk[u] >> ls) * (128 * S) + 4 * S * k + 4 * (blk[u] & (S - 1));
         if constexpr (TAIL) {
           const size_t idx = blk[u] * 128 + 4 * (size_t)k;
           if (idx + 4 <= a.length) {
@@ -428,8 +431,11 @@ __device__ __forceinline__ void touch_bytes(const void *base, size_t byte0, size
   }
 }
 
-template <int B, int MODE, int U, int BS, int PF = 0>
+// LS > 0: the wide layouts (2^LS four-lane groups per block, see UnpackArgs::lane_groups): group g of wide block W is
+// "block" W * 2^LS + g here, its payload vectors and output rows 2^LS apart.  Uniform widths, plain coding only.
+template <int B, int MODE, int U, int BS, int PF = 0, int LS = 0>
 __global__ __launch_bounds__(BS) void k_unpack_fast(UnpackArgs a, uint32_t nwg = 0, uint32_t dist = 0) {
+  static_assert(LS == 0 || (B >= 0 && MODE == MODE_PLAIN), "wide layouts: uniform width, plain coding");
   __shared__ u32x4 lds[BS / 64][2][33];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int h = lane >> 5, k = lane & 31;
@@ -469,7 +475,8 @@ __global__ __launch_bounds__(BS) void k_unpack_fast(UnpackArgs a, uint32_t nwg =
       const size_t blk = first + 2 * (size_t)u;
       if constexpr (B >= 0) {
         b[u] = B;
-        src[u] = reinterpret_cast<const u32x4_u *>(payload + blk * (size_t)B + (k < B ? k : (B ? B - 1 : 0)));
+        const size_t row = (size_t)(k < B ? k : (B ? B - 1 : 0));
+        src[u] = reinterpret_cast<const u32x4_u *>(payload + (((blk >> LS) * (size_t)B) << LS) + (blk & ((1u << LS) - 1)) + (row << LS));
       }
     }
     if constexpr (B >= 0 && MODE != MODE_PLAIN) {
@@ -513,14 +520,16 @@ __global__ __launch_bounds__(BS) void k_unpack_fast(UnpackArgs a, uint32_t nwg =
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const size_t blk = first + 2 * (size_t)u;
-      unpack_finish<B, MODE>(B != 0 ? ld[u] : u32x4{0, 0, 0, 0}, b[u], MODE != MODE_PLAIN ? seed[u] : 0u, slot, k,
-                             a.out + blk * 128 + 4 * k);
+      // 16-lane layout: a store instruction writes 32 bytes of every 64; plain stores let the L2 put them together
+      unpack_finish<B, MODE, LS == 2 ? 2 : 0>(B != 0 ? ld[u] : u32x4{0, 0, 0, 0}, b[u], MODE != MODE_PLAIN ? seed[u] : 0u, slot, k,
+                             a.out + (((blk >> LS) * 128) << LS) + 4 * (blk & ((1u << LS) - 1)) + ((4 * (size_t)k) << LS));
     }
   }
 }
 
-template <int B, int MODE, bool MASKED, int U, int BS>
+template <int B, int MODE, bool MASKED, int U, int BS, int LS = 0>
 __global__ __launch_bounds__(BS) void k_pack_fast(PackArgs a) {
+  static_assert(LS == 0 || (B >= 0 && MODE == MODE_PLAIN), "wide layouts: uniform width, plain coding");
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int h = lane >> 5, k = lane & 31;
   u32x4 *payload = reinterpret_cast<u32x4 *>(a.payload);
@@ -535,10 +544,10 @@ __global__ __launch_bounds__(BS) void k_pack_fast(PackArgs a) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const size_t blk = first + 2 * (size_t)u;
-      x[u] = stream_load(reinterpret_cast<const u32x4 *>(a.in + blk * 128 + 4 * k));
+      x[u] = stream_load(reinterpret_cast<const u32x4 *>(a.in + (((blk >> LS) * 128) << LS) + 4 * (blk & ((1u << LS) - 1)) + ((4 * (size_t)k) << LS)));
       if constexpr (B >= 0) {
         b[u] = B;
-        pbase[u] = reinterpret_cast<uint8_t *>(payload + blk * (size_t)B);
+        pbase[u] = reinterpret_cast<uint8_t *>(payload + (((blk >> LS) * (size_t)B) << LS) + (blk & ((1u << LS) - 1)));
       }
     }
     // Per-block metadata, every lane loading its own block's entry: the encoders are bound by vector-ALU work, and
@@ -622,10 +631,10 @@ __global__ __launch_bounds__(BS) void k_pack_fast(PackArgs a) {
       const uint32_t bu = b[u];
       const uint32_t w = ((uint32_t)k * bu) >> 5;
       if constexpr (B == 32) {
-        *reinterpret_cast<u32x4 *>(pbase[u] + 16 * k) = x[u];
+        *reinterpret_cast<u32x4 *>(pbase[u] + ((16 * k) << LS)) = x[u];
       } else if constexpr (B > 0) {
         const bool last = (k == 31) || ((((uint32_t)(k + 1) * bu) >> 5) != w);
-        if (last) *reinterpret_cast<u32x4 *>(pbase[u] + 16 * w) = acc[u];
+        if (last) *reinterpret_cast<u32x4 *>(pbase[u] + ((16 * w) << LS)) = acc[u];
       } else if constexpr (B < 0) {
         const bool raw = bu == 32;
         const bool last = (k == 31) || ((((uint32_t)(k + 1) * bu) >> 5) != w);
@@ -976,19 +985,20 @@ constexpr int pack_threads(int b) { return (b > 0 && b <= 7 && b != 3) ? 128 : 2
 constexpr int pack_steps(int b) { return b < 0 ? 4 : (b == 3 ? 4 : (b <= 7 ? 2 : 1)); }
 
 // index 0 is the per-block-width instance (B = -1), index 1 + b the uniform width b
-template <int MODE, int BP1>
+template <int MODE, int BP1, int LS = 0>
 static size_t launch_unpack_fast(const UnpackArgs &a, hipStream_t st) {
-  constexpr int U = unpack_steps(BP1 - 1), BS = unpack_threads(BP1 - 1), PF = unpack_prefetch_group(BP1 - 1);
+  // 16-lane layout: two steps, so that a wave's four blocks are the four groups of one wide block
+  constexpr int U = LS == 2 ? 2 : unpack_steps(BP1 - 1), BS = unpack_threads(BP1 - 1), PF = unpack_prefetch_group(BP1 - 1);
   constexpr size_t per_wg = (size_t)(BS / 32) * U;
   const size_t nwg = a.nblocks / per_wg;
   if (nwg == 0) return 0;
   if constexpr (PF > 0) {
     const size_t groups = (nwg + PF - 1) / PF;
     const size_t dist = PREFETCH_DISTANCE_BYTES / (PF * per_wg * 512);
-    hipLaunchKernelGGL((k_unpack_fast<BP1 - 1, MODE, U, BS, PF>), dim3((unsigned)(groups * (PF + 1))), dim3(BS), 0, st, a,
+    hipLaunchKernelGGL((k_unpack_fast<BP1 - 1, MODE, U, BS, PF, LS>), dim3((unsigned)(groups * (PF + 1))), dim3(BS), 0, st, a,
                        (uint32_t)nwg, (uint32_t)dist);
   } else {
-    hipLaunchKernelGGL((k_unpack_fast<BP1 - 1, MODE, U, BS, 0>), dim3((unsigned)nwg), dim3(BS), 0, st, a, 0u, 0u);
+    hipLaunchKernelGGL((k_unpack_fast<BP1 - 1, MODE, U, BS, 0, LS>), dim3((unsigned)nwg), dim3(BS), 0, st, a, 0u, 0u);
   }
   return nwg * per_wg;
 }
@@ -998,6 +1008,14 @@ static size_t dispatch_unpack_fast(int idx, const UnpackArgs &a, hipStream_t st,
   using fn_t = size_t (*)(const UnpackArgs &, hipStream_t);
   static const fn_t table[] = {&launch_unpack_fast<MODE, Is>...};
   return table[idx](a, st);
+}
+
+// wide layouts: widths 0..32 (index = width), plain coding
+template <int LS, int... Is>
+static size_t dispatch_unpack_wide(int bit, const UnpackArgs &a, hipStream_t st, std::integer_sequence<int, Is...>) {
+  using fn_t = size_t (*)(const UnpackArgs &, hipStream_t);
+  static const fn_t table[] = {&launch_unpack_fast<MODE_PLAIN, Is + 1, LS>...};
+  return table[bit](a, st);
 }
 
 static void launch_unpack_flex(int mode, bool tail, const UnpackArgs &a, hipStream_t st) {
@@ -1019,18 +1037,22 @@ hipError_t launch_unpack(int mode, bool tail, const UnpackArgs &a, hipStream_t s
   const bool mixed = a.bits != nullptr && a.off != nullptr;
   const bool uniform = a.bits == nullptr && a.off == nullptr;
   const bool seeds_ok = mode == MODE_PLAIN || a.seeds != nullptr;
-  if (tail || !(mixed || uniform) || !seeds_ok || a.lane_groups > 1) {
+  const bool wide = a.lane_groups > 1;
+  if (tail || !(mixed || uniform) || !seeds_ok || (wide && !(uniform && mode == MODE_PLAIN && (a.lane_groups == 2 || a.lane_groups == 4)))) {
     launch_unpack_flex(mode, tail, a, st);
     return hipGetLastError();
   }
   using seq = std::make_integer_sequence<int, 34>;
+  using wseq = std::make_integer_sequence<int, 33>;
   const int idx = mixed ? 0 : 1 + (int)a.bit;
   UnpackArgs r = a;
   while (r.nblocks) {
     UnpackArgs c = r;
     if (c.nblocks > MAX_BLOCKS_PER_LAUNCH) c.nblocks = MAX_BLOCKS_PER_LAUNCH;
     size_t done;
-    if (mode == MODE_PLAIN) done = dispatch_unpack_fast<MODE_PLAIN>(idx, c, st, seq{});
+    // (a workgroup's blocks are a multiple of four, so whole wide blocks: what is left over starts on one as well)
+    if (wide) done = a.lane_groups == 2 ? dispatch_unpack_wide<1>((int)a.bit, c, st, wseq{}) : dispatch_unpack_wide<2>((int)a.bit, c, st, wseq{});
+    else if (mode == MODE_PLAIN) done = dispatch_unpack_fast<MODE_PLAIN>(idx, c, st, seq{});
     else if (mode == MODE_D1) done = dispatch_unpack_fast<MODE_D1>(idx, c, st, seq{});
     else done = dispatch_unpack_fast<MODE_FOR>(idx, c, st, seq{});
     if (done == 0) {  // fewer blocks than one workgroup handles: ragged end
@@ -1052,12 +1074,12 @@ hipError_t launch_unpack(int mode, bool tail, const UnpackArgs &a, hipStream_t s
   return hipGetLastError();
 }
 
-template <int MODE, bool MASKED, int BP1>
+template <int MODE, bool MASKED, int BP1, int LS = 0>
 static size_t launch_pack_fast(const PackArgs &a, hipStream_t st) {
   constexpr int U = pack_steps(BP1 - 1), BS = pack_threads(BP1 - 1);
   constexpr size_t per_wg = (size_t)(BS / 32) * U;
   const size_t nwg = a.nblocks / per_wg;
-  if (nwg) hipLaunchKernelGGL((k_pack_fast<BP1 - 1, MODE, MASKED, U, BS>), dim3((unsigned)nwg), dim3(BS), 0, st, a);
+  if (nwg) hipLaunchKernelGGL((k_pack_fast<BP1 - 1, MODE, MASKED, U, BS, LS>), dim3((unsigned)nwg), dim3(BS), 0, st, a);
   return nwg * per_wg;
 }
 
@@ -1066,6 +1088,13 @@ static size_t dispatch_pack_fast(int idx, const PackArgs &a, hipStream_t st, std
   using fn_t = size_t (*)(const PackArgs &, hipStream_t);
   static const fn_t table[] = {&launch_pack_fast<MODE, MASKED, Is>...};
   return table[idx](a, st);
+}
+
+template <bool MASKED, int LS, int... Is>
+static size_t dispatch_pack_wide(int bit, const PackArgs &a, hipStream_t st, std::integer_sequence<int, Is...>) {
+  using fn_t = size_t (*)(const PackArgs &, hipStream_t);
+  static const fn_t table[] = {&launch_pack_fast<MODE_PLAIN, MASKED, Is + 1, LS>...};
+  return table[bit](a, st);
 }
 
 static void launch_pack_flex(int mode, bool masked, bool generic, const PackArgs &a, hipStream_t st) {
@@ -1091,18 +1120,23 @@ hipError_t launch_pack(int mode, bool masked, bool generic, const PackArgs &a, h
   const bool uniform = a.bits == nullptr && a.off == nullptr;
   const bool seeds_ok = mode != MODE_FOR || a.seeds != nullptr;
   if (mode == MODE_FOR) masked = false;
-  if (generic || !(mixed || uniform) || !seeds_ok || a.lane_groups > 1) {
+  const bool wide = a.lane_groups > 1;
+  if (generic || !(mixed || uniform) || !seeds_ok || (wide && !(uniform && mode == MODE_PLAIN && (a.lane_groups == 2 || a.lane_groups == 4)))) {
     launch_pack_flex(mode, masked, generic, a, st);
     return hipGetLastError();
   }
   using seq = std::make_integer_sequence<int, 34>;
+  using wseq = std::make_integer_sequence<int, 33>;
   const int idx = mixed ? 0 : 1 + (int)a.bit;
   PackArgs r = a;
   while (r.nblocks) {
     PackArgs c = r;
     if (c.nblocks > MAX_BLOCKS_PER_LAUNCH) c.nblocks = MAX_BLOCKS_PER_LAUNCH;
     size_t done;
-    if (mode == MODE_PLAIN) {
+    if (wide) {
+      if (a.lane_groups == 2) done = masked ? dispatch_pack_wide<true, 1>((int)a.bit, c, st, wseq{}) : dispatch_pack_wide<false, 1>((int)a.bit, c, st, wseq{});
+      else done = masked ? dispatch_pack_wide<true, 2>((int)a.bit, c, st, wseq{}) : dispatch_pack_wide<false, 2>((int)a.bit, c, st, wseq{});
+    } else if (mode == MODE_PLAIN) {
       done = masked ? dispatch_pack_fast<MODE_PLAIN, true>(idx, c, st, seq{})
                     : dispatch_pack_fast<MODE_PLAIN, false>(idx, c, st, seq{});
     } else if (mode == MODE_D1) {
