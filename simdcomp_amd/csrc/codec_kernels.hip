@@ -457,7 +457,9 @@ __global__ __launch_bounds__(BS) void k_unpack_fast(UnpackArgs a, uint32_t nwg =
       for (size_t t = t0; t < t1; ++t) {
         if (t * GB >= nblk) break;
         touch_bytes<BS, GB * B * 16>(a.payload, t * GB * B * 16, nblk * B * 16 - 1, acc);
-        if constexpr (MODE != MODE_PLAIN) touch_bytes<BS, GB * 4>(a.seeds, t * GB * 4, nblk * 4 - 1, acc);
+        // (no seed array: the same bytes of the payload are touched instead, which keeps this path free of branches)
+        if constexpr (MODE != MODE_PLAIN)
+          touch_bytes<BS, GB * 4>(a.seeds ? static_cast<const void *>(a.seeds) : a.payload, t * GB * 4, nblk * 4 - 1, acc);
       }
       asm volatile("" ::"v"(acc));  // keeps the loads; the only wait of this workgroup
       return;
@@ -481,7 +483,13 @@ __global__ __launch_bounds__(BS) void k_unpack_fast(UnpackArgs a, uint32_t nwg =
     }
     if constexpr (B >= 0 && MODE != MODE_PLAIN) {
       // the seeds of the wave's 2 * U consecutive blocks: one coalesced load, handed out through scalar registers
-      hand_out<U>(a.seeds[tile * per_iter + (size_t)wv * 2 * U + (size_t)(lane % (2 * U))], h, seed);
+      // (no array: one offset / base for every block, as in the *_length forms)
+      if (a.seeds) {
+        hand_out<U>(a.seeds[tile * per_iter + (size_t)wv * 2 * U + (size_t)(lane % (2 * U))], h, seed);
+      } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u) seed[u] = a.seed0;
+      }
     }
     if constexpr (B < 0) {
       // width, offset and seed of the wave's 2 * U consecutive blocks: one coalesced load per array, side by side
@@ -527,9 +535,13 @@ __global__ __launch_bounds__(BS) void k_unpack_fast(UnpackArgs a, uint32_t nwg =
   }
 }
 
-template <int B, int MODE, bool MASKED, int U, int BS, int LS = 0>
+// GENERIC: full blocks of the reference's arbitrary-length frame-of-reference packer (src/simdfor.c:15043
+// simdpackFOR_length): a field that ends exactly on a word boundary still hands value >> b to the next word, across
+// block boundaries too (visible only for out-of-range input).  The partial last block stays with k_pack_flex.
+template <int B, int MODE, bool MASKED, int U, int BS, int LS = 0, bool GENERIC = false>
 __global__ __launch_bounds__(BS) void k_pack_fast(PackArgs a) {
   static_assert(LS == 0 || (B >= 0 && MODE == MODE_PLAIN), "wide layouts: uniform width, plain coding");
+  static_assert(!GENERIC || (B > 0 && B < 32 && MODE == MODE_FOR && !MASKED && LS == 0), "generic: FOR, widths 1..31");
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int h = lane >> 5, k = lane & 31;
   u32x4 *payload = reinterpret_cast<u32x4 *>(a.payload);
@@ -566,8 +578,20 @@ __global__ __launch_bounds__(BS) void k_pack_fast(PackArgs a) {
         seed[u] = *sp;
         if (!a.seeds && start) seed[u] = a.seed0;
       } else if constexpr (MODE == MODE_FOR) {
-        seed[u] = a.seeds[blk];
+        // (no array: one base for every block, as in simdpackFOR_length; read from g_nothing to stay branch-free)
+        const uint32_t sd = load_global_as<uint32_t>(a.seeds ? reinterpret_cast<uintptr_t>(a.seeds + blk)
+                                                             : reinterpret_cast<uintptr_t>(&g_nothing));
+        seed[u] = a.seeds ? sd : a.seed0;
       }
+    }
+    // GENERIC: what the last row of the block in front hands to this block's first word.  For the wave's first block
+    // it comes from memory, for the others from the neighbouring half-wave (below).
+    u32x4 handed = {0, 0, 0, 0};
+    if constexpr (GENERIC) {
+      const size_t wb = tile * per_iter + (size_t)wv * 2 * U;
+      const bool has_prev = wb > 0 || a.carry_first;
+      const u32x4 last_row = *reinterpret_cast<const u32x4 *>(a.in + (has_prev ? wb * 128 - 4 : 0));
+      handed = has_prev ? ((last_row - seed[0]) >> (uint32_t)B) : handed;
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -584,13 +608,23 @@ __global__ __launch_bounds__(BS) void k_pack_fast(PackArgs a) {
       const uint32_t p = (uint32_t)k * bu, w = p >> 5, s = p & 31;
       u32x4 t = v << s;
       const uint32_t back = (32 - s) & 31;
-      const uint32_t keep = (s + bu > 32) ? 0xFFFFFFFFu : 0u;
+      const uint32_t keep = (GENERIC ? (s + bu >= 32) : (s + bu > 32)) ? 0xFFFFFFFFu : 0u;
       u32x4 sp = (v >> back) & keep;
-      const uint32_t notfirst = k == 0 ? 0u : 0xFFFFFFFFu;
-      t.x |= dpp0<DPP_WAVE_SHR1>(sp.x) & notfirst;
-      t.y |= dpp0<DPP_WAVE_SHR1>(sp.y) & notfirst;
-      t.z |= dpp0<DPP_WAVE_SHR1>(sp.z) & notfirst;
-      t.w |= dpp0<DPP_WAVE_SHR1>(sp.w) & notfirst;
+      if constexpr (GENERIC) {
+        // lane 32 takes lane 31's hand-over as it comes (the block in front is the other half-wave's); lane 0 takes
+        // what lane 63 handed over at the step before, or `handed` at the first step
+        u32x4 fp = {dpp0<DPP_WAVE_SHR1>(sp.x), dpp0<DPP_WAVE_SHR1>(sp.y), dpp0<DPP_WAVE_SHR1>(sp.z), dpp0<DPP_WAVE_SHR1>(sp.w)};
+        fp = lane == 0 ? handed : fp;
+        t |= fp;
+        handed = u32x4{(uint32_t)__builtin_amdgcn_readlane((int)sp.x, 63), (uint32_t)__builtin_amdgcn_readlane((int)sp.y, 63),
+                       (uint32_t)__builtin_amdgcn_readlane((int)sp.z, 63), (uint32_t)__builtin_amdgcn_readlane((int)sp.w, 63)};
+      } else {
+        const uint32_t notfirst = k == 0 ? 0u : 0xFFFFFFFFu;
+        t.x |= dpp0<DPP_WAVE_SHR1>(sp.x) & notfirst;
+        t.y |= dpp0<DPP_WAVE_SHR1>(sp.y) & notfirst;
+        t.z |= dpp0<DPP_WAVE_SHR1>(sp.z) & notfirst;
+        t.w |= dpp0<DPP_WAVE_SHR1>(sp.w) & notfirst;
+      }
 #define SC_SEG_STEP(D, CTRL)                                                          \
   if constexpr (B < 0 || D < max_rows_per_word(B)) {                                  \
     const uint32_t same = ((((uint32_t)(k - D) * bu) >> 5) == w) ? 0xFFFFFFFFu : 0u;   \
@@ -1036,7 +1070,7 @@ hipError_t launch_unpack(int mode, bool tail, const UnpackArgs &a, hipStream_t s
   if (a.nblocks == 0) return hipSuccess;
   const bool mixed = a.bits != nullptr && a.off != nullptr;
   const bool uniform = a.bits == nullptr && a.off == nullptr;
-  const bool seeds_ok = mode == MODE_PLAIN || a.seeds != nullptr;
+  const bool seeds_ok = mode == MODE_PLAIN || a.seeds != nullptr || uniform;  // uniform widths: seed0 serves every block
   const bool wide = a.lane_groups > 1;
   if (tail || !(mixed || uniform) || !seeds_ok || (wide && !(uniform && mode == MODE_PLAIN && (a.lane_groups == 2 || a.lane_groups == 4)))) {
     launch_unpack_flex(mode, tail, a, st);
@@ -1074,12 +1108,12 @@ hipError_t launch_unpack(int mode, bool tail, const UnpackArgs &a, hipStream_t s
   return hipGetLastError();
 }
 
-template <int MODE, bool MASKED, int BP1, int LS = 0>
+template <int MODE, bool MASKED, int BP1, int LS = 0, bool GENERIC = false>
 static size_t launch_pack_fast(const PackArgs &a, hipStream_t st) {
   constexpr int U = pack_steps(BP1 - 1), BS = pack_threads(BP1 - 1);
   constexpr size_t per_wg = (size_t)(BS / 32) * U;
   const size_t nwg = a.nblocks / per_wg;
-  if (nwg) hipLaunchKernelGGL((k_pack_fast<BP1 - 1, MODE, MASKED, U, BS, LS>), dim3((unsigned)nwg), dim3(BS), 0, st, a);
+  if (nwg) hipLaunchKernelGGL((k_pack_fast<BP1 - 1, MODE, MASKED, U, BS, LS, GENERIC>), dim3((unsigned)nwg), dim3(BS), 0, st, a);
   return nwg * per_wg;
 }
 
@@ -1095,6 +1129,14 @@ static size_t dispatch_pack_wide(int bit, const PackArgs &a, hipStream_t st, std
   using fn_t = size_t (*)(const PackArgs &, hipStream_t);
   static const fn_t table[] = {&launch_pack_fast<MODE_PLAIN, MASKED, Is + 1, LS>...};
   return table[bit](a, st);
+}
+
+// full blocks of simdpackFOR_length: widths 1..31 (index = width - 1)
+template <int... Is>
+static size_t dispatch_pack_generic_for(int bit, const PackArgs &a, hipStream_t st, std::integer_sequence<int, Is...>) {
+  using fn_t = size_t (*)(const PackArgs &, hipStream_t);
+  static const fn_t table[] = {&launch_pack_fast<MODE_FOR, false, Is + 2, 0, true>...};
+  return table[bit - 1](a, st);
 }
 
 static void launch_pack_flex(int mode, bool masked, bool generic, const PackArgs &a, hipStream_t st) {
@@ -1118,9 +1160,31 @@ hipError_t launch_pack(int mode, bool masked, bool generic, const PackArgs &a, h
   if (a.nblocks == 0) return hipSuccess;
   const bool mixed = a.bits != nullptr && a.off != nullptr;
   const bool uniform = a.bits == nullptr && a.off == nullptr;
-  const bool seeds_ok = mode != MODE_FOR || a.seeds != nullptr;
+  const bool seeds_ok = mode != MODE_FOR || a.seeds != nullptr || uniform;  // uniform widths: seed0 serves every block
   if (mode == MODE_FOR) masked = false;
   const bool wide = a.lane_groups > 1;
+  if (generic && mode == MODE_FOR && uniform && !a.seeds && !wide && a.carry_blocks && a.bit >= 1 && a.bit <= 31 && a.length >= 128) {
+    // simdpackFOR_length: the full blocks through the fast kernels, what is left (ragged end of the workgroup
+    // tiling, partial last block) through the flexible kernel, which is told that blocks lie in front of it
+    PackArgs r = a;
+    size_t full = a.length / 128;
+    while (full) {
+      PackArgs c = r;
+      c.nblocks = full > MAX_BLOCKS_PER_LAUNCH ? MAX_BLOCKS_PER_LAUNCH : full;
+      c.length = c.nblocks * 128;
+      const size_t done = dispatch_pack_generic_for((int)a.bit, c, st, std::make_integer_sequence<int, 31>{});
+      if (done == 0) break;
+      full -= done;
+      r.nblocks -= done;
+      r.length -= done * 128;
+      r.in += done * 128;
+      r.carry_first = true;
+      if (r.seeds) r.seeds += done;
+      r.payload = static_cast<uint8_t *>(r.payload) + done * 16 * (size_t)a.bit;
+    }
+    if (r.nblocks) launch_pack_flex(mode, masked, true, r, st);
+    return hipGetLastError();
+  }
   if (generic || !(mixed || uniform) || !seeds_ok || (wide && !(uniform && mode == MODE_PLAIN && (a.lane_groups == 2 || a.lane_groups == 4)))) {
     launch_pack_flex(mode, masked, generic, a, st);
     return hipGetLastError();

@@ -200,11 +200,11 @@ def test_mixed_widths(dev, orc):
 
 @pytest.mark.parametrize("bit", BITS)
 def test_lengths(dev, orc, bit):
-    full = {"inrange": synth.random_bits(60, 5000, bit), "wild": synth.rand_u32(61, 5000)}
+    full = {"inrange": synth.random_bits(60, 20011, bit), "wild": synth.rand_u32(61, 20011)}
     import torch
 
     for name, data in full.items():
-        for n in [0, 1, 2, 3, 4, 5, 7, 8, 31, 127, 128, 129, 130, 255, 256, 257, 1000, 4095, 4097, 5000]:
+        for n in [0, 1, 2, 3, 4, 5, 7, 8, 31, 127, 128, 129, 130, 255, 256, 257, 1000, 4095, 4097, 5000, 20011]:
             x = data[:n].copy()
             want = orc.simdpack_length(x, bit)
             nbytes = dev.compressedbytes(n, bit)
