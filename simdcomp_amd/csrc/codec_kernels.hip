@@ -481,16 +481,6 @@ __global__ __launch_bounds__(BS) void k_unpack_fast(UnpackArgs a, uint32_t nwg =
         src[u] = reinterpret_cast<const u32x4_u *>(payload + (((blk >> LS) * (size_t)B) << LS) + (blk & ((1u << LS) - 1)) + (row << LS));
       }
     }
-    if constexpr (B >= 0 && MODE != MODE_PLAIN) {
-      // the seeds of the wave's 2 * U consecutive blocks: one coalesced load, handed out through scalar registers
-      // (no array: one offset / base for every block, as in the *_length forms)
-      if (a.seeds) {
-        hand_out<U>(a.seeds[tile * per_iter + (size_t)wv * 2 * U + (size_t)(lane % (2 * U))], h, seed);
-      } else {
-#pragma unroll
-        for (int u = 0; u < U; ++u) seed[u] = a.seed0;
-      }
-    }
     if constexpr (B < 0) {
       // width, offset and seed of the wave's 2 * U consecutive blocks: one coalesced load per array, side by side
       // (12 memory instructions fewer per wave than per-lane loads: 9 points of HBM peak).  The payload address
@@ -524,6 +514,18 @@ __global__ __launch_bounds__(BS) void k_unpack_fast(UnpackArgs a, uint32_t nwg =
     if constexpr (B != 0) {
 #pragma unroll
       for (int u = 0; u < U; ++u) ld[u] = load_global_at(reinterpret_cast<uintptr_t>(src[u]));
+    }
+    if constexpr (B >= 0 && MODE != MODE_PLAIN) {
+      // The seeds of the wave's 2 * U consecutive blocks: one coalesced load, handed out through scalar registers.
+      // It goes out behind the payload loads and without a branch of its own (no array -- one offset / base for every
+      // block, as in the *_length forms -- reads g_nothing instead): a wait for it in front of the payload loads
+      // would put two memory latencies in a row (measured: 80 -> 60-70 % of peak for widths 15..31).
+      const size_t mine = tile * per_iter + (size_t)wv * 2 * U + (size_t)(lane % (2 * U));
+      const uint32_t ms = load_global_as<uint32_t>(a.seeds ? reinterpret_cast<uintptr_t>(a.seeds + mine)
+                                                           : reinterpret_cast<uintptr_t>(&g_nothing));
+      hand_out<U>(ms, h, seed);
+#pragma unroll
+      for (int u = 0; u < U; ++u) seed[u] = a.seeds ? seed[u] : a.seed0;
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
