@@ -44,7 +44,7 @@ def main():
         w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
         w.writeheader()
         w.writerows(keep)
-    pat = r"k_unpack_fast<(\d+), 1, \d+, \d+, \d+>"
+    pat = r"k_unpack_fast<(\d+), 1, \d+, \d+, \d+(?:, \d+)?>"
     fd, wd = per_width(fetch, pat), per_width(write, pat)
     table = {}
     for b in sorted(fd):
