@@ -575,15 +575,28 @@ __global__ __launch_bounds__(BS) void k_pack_fast(PackArgs a) {
       }
       if constexpr (MODE == MODE_D1) {
         // explicit seeds, or chained from the input: block k starts from in[128k-1], block 0 from seed0
+        // (address chosen by arithmetic, value chosen after the load: no branch in front of it)
         const bool start = blk == 0 && a.chain_base == 0;  // first block of the whole stream
-        const uint32_t *sp = a.seeds ? a.seeds + blk : a.in + (start ? 0 : blk * 128 - 1);
-        seed[u] = *sp;
-        if (!a.seeds && start) seed[u] = a.seed0;
+        const uintptr_t at = a.seeds ? reinterpret_cast<uintptr_t>(a.seeds + blk)
+                                     : reinterpret_cast<uintptr_t>(a.in + (start ? 0 : blk * 128 - 1));
+        seed[u] = load_global_as<uint32_t>(at);
       } else if constexpr (MODE == MODE_FOR) {
         // (no array: one base for every block, as in simdpackFOR_length; read from g_nothing to stay branch-free)
-        const uint32_t sd = load_global_as<uint32_t>(a.seeds ? reinterpret_cast<uintptr_t>(a.seeds + blk)
-                                                             : reinterpret_cast<uintptr_t>(&g_nothing));
-        seed[u] = a.seeds ? sd : a.seed0;
+        seed[u] = load_global_as<uint32_t>(a.seeds ? reinterpret_cast<uintptr_t>(a.seeds + blk)
+                                                   : reinterpret_cast<uintptr_t>(&g_nothing));
+      }
+    }
+    // Nothing moves across this line, and nothing above it uses a loaded value: otherwise the scheduler issues the
+    // seed loads of the later steps only after it has waited for the first step's integers (one in-order counter),
+    // which puts a second memory latency behind the first.
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if constexpr (MODE == MODE_D1) {
+        const bool start = first + 2 * (size_t)u == 0 && a.chain_base == 0;
+        seed[u] = (!a.seeds && start) ? a.seed0 : seed[u];
+      } else if constexpr (MODE == MODE_FOR) {
+        seed[u] = a.seeds ? seed[u] : a.seed0;
       }
     }
     // GENERIC: what the last row of the block in front hands to this block's first word.  For the wave's first block
@@ -593,7 +606,8 @@ __global__ __launch_bounds__(BS) void k_pack_fast(PackArgs a) {
       const size_t wb = tile * per_iter + (size_t)wv * 2 * U;
       const bool has_prev = wb > 0 || a.carry_first;
       const u32x4 last_row = *reinterpret_cast<const u32x4 *>(a.in + (has_prev ? wb * 128 - 4 : 0));
-      handed = has_prev ? ((last_row - seed[0]) >> (uint32_t)B) : handed;
+      // (masked, not chosen: a choice would move the load under the condition, behind a wait of its own)
+      handed = ((last_row - seed[0]) >> (uint32_t)B) & (has_prev ? 0xFFFFFFFFu : 0u);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
