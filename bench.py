@@ -24,7 +24,12 @@ Extra objects on the JSON line:
                 sample, 1 thread (and all cores as `all_cores`);
   encode        simdpackwithoutmaskd1 over the same corpus (rank 0's GPU, outside
                 the timed steps), output compared byte for byte with the payload;
-  host_to_host  the same decode including pinned H2D/D2H copies (rank 0 only).
+  callers       example.c's compress() and decode loop over the [width byte][payload]
+                stream as one device call each, and a batched simdsearchwithlengthd1,
+                on a mixed-width corpus; round trip and answers checked in place;
+  host_to_host  the same decode including pinned H2D/D2H copies.
+The legs beside the headline number (cpu_baseline, callers, host_to_host) run at
+N = 1 only.
 """
 import argparse
 import json
@@ -248,6 +253,77 @@ def cpu_callers(orc, codec, log2n=24):
             "sample": f"2^{log2n} docIDs, widths 1..20; 2^20 searches with a random block each"}
 
 
+def callers_leg(dev, log2n):
+    """The callers either side of the block codec, device-resident, on a mixed-width d1 corpus (widths 0..20 skewed
+    small, mean ~7.5): compress() of example.c:56-75 and its decode loop :101-110 as one call each over the
+    [width byte][payload] stream, and simdsearchwithlengthd1 as one batched launch.  The round trip and the search
+    answers are checked here; the CPU counterparts are in cpu_baseline.callers."""
+    L, P = binding.lib(), binding.ptr
+    st = torch.cuda.current_stream().cuda_stream
+    n = 1 << log2n
+    nblk = n // 128
+    g = torch.Generator(device=dev)
+    g.manual_seed(77)
+    w = torch.minimum(torch.randint(0, 21, (nblk,), device=dev, generator=g), torch.randint(0, 21, (nblk,), device=dev, generator=g))
+    gaps = torch.randint(0, 1 << 30, (n,), dtype=torch.int32, device=dev, generator=g)
+    gaps &= ((1 << w) - 1).to(torch.int32).repeat_interleave(128)
+    ids = torch.cumsum(gaps, 0, dtype=torch.int32)
+    del gaps, w
+
+    def best(f, reps=5):
+        f()
+        torch.cuda.synchronize()
+        t = 1e9
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            f()
+            e1.record()
+            e1.synchronize()
+            t = min(t, e0.elapsed_time(e1) * 1e-3)
+        return t
+
+    buf = torch.empty(nblk * 513 + 16, dtype=torch.uint8, device=dev)
+    nbytes = torch.zeros(1, dtype=torch.int64, device=dev)
+    ws_c = torch.empty(max(16, L.simdcomp_hip_stream_compress_workspace(nblk)), dtype=torch.uint8, device=dev)
+    t_c = best(lambda: binding.check(L.simdcomp_hip_stream_compress(1, 0, P(ids), nblk, P(buf), P(nbytes), P(ws_c), st), "compress"))
+    T = int(nbytes.item())
+    out = torch.empty(n, dtype=torch.int32, device=dev)
+    res = torch.zeros(3, dtype=torch.int64, device=dev)
+    ws_d = torch.empty(max(16, L.simdcomp_hip_stream_decode_workspace(T, nblk)), dtype=torch.uint8, device=dev)
+    t_d = best(lambda: binding.check(L.simdcomp_hip_stream_decode(1, 0, P(buf), T, nblk, P(out), P(res), P(ws_d), st), "decode"))
+    ok = bool(torch.equal(out, ids)) and res.tolist() == [nblk, T - nblk, 0]
+    del out, ws_c, ws_d
+
+    bits, off, _ = codec.stream_index(buf[:T], nblk)
+    seeds = codec.chain_offsets(buf, bits, off, stream_layout=True)
+    nq = 1 << 24
+    qb = torch.randint(0, nblk, (nq,), dtype=torch.int64, device=dev, generator=g)
+    slot = torch.randint(0, 128, (nq,), dtype=torch.int64, device=dev, generator=g)
+    keys = ids[qb * 128 + slot]  # a key that is present: the answer is the first position holding it
+    pos = val = None
+
+    def run_search():
+        nonlocal pos, val
+        pos, val = codec.search(1, buf, keys, bits=bits, offsets=off, initvalues=seeds, query_blocks=qb, stream_layout=True)
+
+    t_s = best(run_search, reps=3)
+    nv = 1 << 20  # answers checked on the first 2^20 queries
+    qb, keys, pos, val = qb[:nv], keys[:nv], pos[:nv], val[:nv]
+    blockvals = ids.view(nblk, 128)[qb]
+    # the first position whose value is >= key (unsigned): for sorted blocks that is the first occurrence of the key
+    u = lambda x: x.to(torch.int64) & 0xFFFFFFFF
+    first = (u(blockvals) >= u(keys)[:, None]).to(torch.int8).argmax(dim=1)
+    sorted_block = (u(blockvals[:, 1:]) >= u(blockvals[:, :-1])).all(dim=1)
+    search_ok = bool(torch.equal(pos.to(torch.int64)[sorted_block], first[sorted_block])) and \
+        bool(torch.equal(val[sorted_block], keys[sorted_block])) and int(sorted_block.sum()) > nv // 2
+    return {"corpus": f"2^{log2n} docIDs, widths 0..20, {T / nblk / 16:.2f} bits per integer, {T >> 20} MiB of stream",
+            "stream_compress": {"ms": round(t_c * 1e3, 4), "int32/s": n / t_c},
+            "stream_decode": {"ms": round(t_d * 1e3, 4), "int32/s": n / t_d},
+            "round_trip_ok": ok,
+            "search": {"queries": nq, "ms": round(t_s * 1e3, 4), "queries/s": nq / t_s, "answers_ok": search_ok}}
+
+
 def host_to_host(dev, log2n=28, widths=(1, 8, 16, 32)):
     """Decode that starts and ends in pinned host memory: H2D payload+offsets,
     kernel, D2H integers, pipelined in 2^24-integer pieces over two streams."""
@@ -295,6 +371,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-h2h", action="store_true", help="skip the host-to-host leg")
     ap.add_argument("--no-encode", action="store_true", help="skip the encoder leg")
+    ap.add_argument("--no-callers", action="store_true", help="skip the stream / search leg")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -406,11 +483,16 @@ def main():
         if not a.no_encode:
             del out
             line["encode"] = encode_leg(corpora, nblocks, seed0, dev)
-        if not a.no_cpu:
+        # the legs beside the headline number run at N = 1 only: at N > 1 the other ranks would sit in the final
+        # barrier while rank 0 works
+        if not a.no_cpu and world == 1:
             line["cpu_baseline"] = cpu_baseline()
-        if not a.no_h2h:
-            del corpora
+        del corpora
+        torch.cuda.empty_cache()
+        if not a.no_callers and world == 1:
+            line["callers"] = callers_leg(dev, a.log2n)
             torch.cuda.empty_cache()
+        if not a.no_h2h and world == 1:
             line["host_to_host"] = host_to_host(dev)
         print(json.dumps(line), flush=True)
     if distributed:
