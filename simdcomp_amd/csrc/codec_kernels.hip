@@ -643,7 +643,8 @@ __global__ __launch_bounds__(BS) void k_pack_fast(PackArgs a) {
       }
 #define SC_SEG_STEP(D, CTRL)                                                          \
   if constexpr (B < 0 || D < max_rows_per_word(B)) {                                  \
-    const uint32_t same = ((((uint32_t)(k - D) * bu) >> 5) == w) ? 0xFFFFFFFFu : 0u;   \
+    /* row k - D starts in this row's word iff D * b <= s (s = this row's bit offset in the word) */ \
+    const uint32_t same = ((uint32_t)D * bu <= s) ? 0xFFFFFFFFu : 0u;                  \
     t.x |= dpp0<CTRL>(t.x) & same;                                                    \
     t.y |= dpp0<CTRL>(t.y) & same;                                                    \
     t.z |= dpp0<CTRL>(t.z) & same;                                                    \
