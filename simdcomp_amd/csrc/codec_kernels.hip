@@ -286,11 +286,12 @@ __global__ __launch_bounds__(256) void k_pack_flex(PackArgs a) {
       const uint32_t w15 = (15u * bu) >> 5;
 #define SC_SEG_STEP(D, CTRL)                                                             \
   if (B < 0 || D < max_rows_per_word(B)) {                                               \
-    const uint32_t same = ((((uint32_t)(k - D) * bu) >> 5) == w) ? 0xFFFFFFFFu : 0u;      \
-    acc.x |= dpp0<CTRL>(acc.x) & same;                                                   \
-    acc.y |= dpp0<CTRL>(acc.y) & same;                                                   \
-    acc.z |= dpp0<CTRL>(acc.z) & same;                                                   \
-    acc.w |= dpp0<CTRL>(acc.w) & same;                                                   \
+    /* masked at the giving lane (row k + D starts in the same word iff D * b <= its bit offset): see k_pack_fast */ \
+    const uint32_t give = ((uint32_t)D * bu <= ((((uint32_t)k + D) * bu) & 31u)) ? 0xFFFFFFFFu : 0u; \
+    acc.x |= dpp0<CTRL>(acc.x & give);                                                   \
+    acc.y |= dpp0<CTRL>(acc.y & give);                                                   \
+    acc.z |= dpp0<CTRL>(acc.z & give);                                                   \
+    acc.w |= dpp0<CTRL>(acc.w & give);                                                   \
   }
       SC_SEG_STEP(1, DPP_ROW_SHR1)
       SC_SEG_STEP(2, DPP_ROW_SHR2)
@@ -635,20 +636,24 @@ __global__ __launch_bounds__(BS) void k_pack_fast(PackArgs a) {
         handed = u32x4{(uint32_t)__builtin_amdgcn_readlane((int)sp.x, 63), (uint32_t)__builtin_amdgcn_readlane((int)sp.y, 63),
                        (uint32_t)__builtin_amdgcn_readlane((int)sp.z, 63), (uint32_t)__builtin_amdgcn_readlane((int)sp.w, 63)};
       } else {
-        const uint32_t notfirst = k == 0 ? 0u : 0xFFFFFFFFu;
-        t.x |= dpp0<DPP_WAVE_SHR1>(sp.x) & notfirst;
-        t.y |= dpp0<DPP_WAVE_SHR1>(sp.y) & notfirst;
-        t.z |= dpp0<DPP_WAVE_SHR1>(sp.z) & notfirst;
-        t.w |= dpp0<DPP_WAVE_SHR1>(sp.w) & notfirst;
+        // (row 0 takes nothing: lane 0 has no lane in front of it, and lane 32's neighbour, row 31 of the other
+        // block, ends exactly on a word boundary -- 32 * b bits -- so its spill is zero by `keep`)
+        t.x |= dpp0<DPP_WAVE_SHR1>(sp.x);
+        t.y |= dpp0<DPP_WAVE_SHR1>(sp.y);
+        t.z |= dpp0<DPP_WAVE_SHR1>(sp.z);
+        t.w |= dpp0<DPP_WAVE_SHR1>(sp.w);
       }
 #define SC_SEG_STEP(D, CTRL)                                                          \
   if constexpr (B < 0 || D < max_rows_per_word(B)) {                                  \
-    /* row k - D starts in this row's word iff D * b <= s (s = this row's bit offset in the word) */ \
-    const uint32_t same = ((uint32_t)D * bu <= s) ? 0xFFFFFFFFu : 0u;                  \
-    t.x |= dpp0<CTRL>(t.x) & same;                                                    \
-    t.y |= dpp0<CTRL>(t.y) & same;                                                    \
-    t.z |= dpp0<CTRL>(t.z) & same;                                                    \
-    t.w |= dpp0<CTRL>(t.w) & same;                                                    \
+    /* Lane j hands its partial word to lane j + D when row j + D starts in the same word, i.e. D * b <= bit */ \
+    /* offset of row j + D.  Masking at the GIVING lane leaves "t |= shifted" for the taker, which the       */ \
+    /* compiler folds into one v_or_b32 with a DPP operand (a mask at the taker costs two more instructions    */ \
+    /* per component: the AND cannot take the DPP operand, its neutral element is not the zero fill).          */ \
+    const uint32_t give = ((uint32_t)D * bu <= ((((uint32_t)k + D) * bu) & 31u)) ? 0xFFFFFFFFu : 0u;            \
+    t.x |= dpp0<CTRL>(t.x & give);                                                     \
+    t.y |= dpp0<CTRL>(t.y & give);                                                     \
+    t.z |= dpp0<CTRL>(t.z & give);                                                     \
+    t.w |= dpp0<CTRL>(t.w & give);                                                     \
   }
       SC_SEG_STEP(1, DPP_ROW_SHR1)
       if constexpr (B < 0) {
@@ -1031,9 +1036,15 @@ constexpr int unpack_steps(int b) { return b < 0 ? SC_MIXED_UNPACK_STEPS : (b <=
 // cost more than they save.
 constexpr int unpack_prefetch_group(int b) { return (b >= 1 && b <= 7) ? 16 : 0; }
 constexpr size_t PREFETCH_DISTANCE_BYTES = (size_t)20 << 20;
-// The encoders read 512 bytes per block whatever the width.
-constexpr int pack_threads(int b) { return (b > 0 && b <= 7 && b != 3) ? 128 : 256; }
-constexpr int pack_steps(int b) { return b < 0 ? 4 : (b == 3 ? 4 : (b <= 7 ? 2 : 1)); }
+// The encoders read 512 bytes per block whatever the width.  Shapes from sweeps at 2^30 integers after the segmented
+// scan was brought down to two instructions per component and step (before that b = 3, five steps, was bound by
+// vector-ALU work and wanted 256 x 4): 128 x 2 for b <= 7, 256 x 1 above, 256 x 2 for per-block widths.
+#ifndef SC_PM_BS
+#define SC_PM_BS 256
+#define SC_PM_U 2
+#endif
+constexpr int pack_threads(int b) { return b < 0 ? SC_PM_BS : ((b > 0 && b <= 7) ? 128 : 256); }
+constexpr int pack_steps(int b) { return b < 0 ? SC_PM_U : (b <= 7 ? 2 : 1); }
 
 // index 0 is the per-block-width instance (B = -1), index 1 + b the uniform width b
 template <int MODE, int BP1, int LS = 0>
