@@ -364,9 +364,8 @@ __global__ __launch_bounds__(256) void k_pack_flex(PackArgs a) {
 
 // Decode one already-loaded block per half-wave: LDS exchange, extraction, the
 // mode's arithmetic, one 16-byte store per thread.  `b` is B when B >= 0.
-template <int B, int MODE, int STORE = 0>
-__device__ __forceinline__ void unpack_finish(const u32x4 ld, const uint32_t b, const uint32_t seed, u32x4 *slot,
-                                              const int k, uint32_t *out_row) {
+template <int B, int MODE>
+__device__ __forceinline__ u32x4 unpack_values(const u32x4 ld, const uint32_t b, const uint32_t seed, u32x4 *slot, const int k) {
   u32x4 v;
   if constexpr (B == 0) {
     v = u32x4{0, 0, 0, 0};
@@ -411,6 +410,13 @@ __device__ __forceinline__ void unpack_finish(const u32x4 ld, const uint32_t b, 
     v.z += add;
     v.w += add;
   }
+  return v;
+}
+
+template <int B, int MODE, int STORE = 0>
+__device__ __forceinline__ void unpack_finish(const u32x4 ld, const uint32_t b, const uint32_t seed, u32x4 *slot,
+                                              const int k, uint32_t *out_row) {
+  const u32x4 v = unpack_values<B, MODE>(ld, b, seed, slot, k);
   if constexpr (STORE == 1) __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(out_row));
   else if constexpr (STORE == 2) *reinterpret_cast<u32x4 *>(out_row) = v;
   else stream_store(reinterpret_cast<u32x4 *>(out_row), v);
@@ -528,12 +534,34 @@ __global__ __launch_bounds__(BS) void k_unpack_fast(UnpackArgs a, uint32_t nwg =
 #pragma unroll
       for (int u = 0; u < U; ++u) seed[u] = a.seeds ? seed[u] : a.seed0;
     }
+    if constexpr (LS == 2) {
+      // 16-lane layout: the wave's four blocks (U = 2) are the four lane groups of ONE wide block, whose 2 KiB of
+      // output interleave them 16 bytes at a time.  Stored from where they are decoded, an instruction would write 32
+      // bytes of every 64; the values go through LDS once more instead (padded rows: no bank conflicts), and every
+      // store instruction writes 1 KiB in one piece.
+      static_assert(U == 2, "16-lane layout: two steps per half-wave");
+      __shared__ u32x4 xch[BS / 64][4][33];
+      u32x4 v[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const size_t blk = first + 2 * (size_t)u;
-      // 16-lane layout: a store instruction writes 32 bytes of every 64; plain stores let the L2 put them together
-      unpack_finish<B, MODE, LS == 2 ? 2 : 0>(B != 0 ? ld[u] : u32x4{0, 0, 0, 0}, b[u], MODE != MODE_PLAIN ? seed[u] : 0u, slot, k,
-                             a.out + (((blk >> LS) * 128) << LS) + 4 * (blk & ((1u << LS) - 1)) + ((4 * (size_t)k) << LS));
+      for (int u = 0; u < U; ++u)
+        v[u] = unpack_values<B, MODE>(B != 0 ? ld[u] : u32x4{0, 0, 0, 0}, b[u], 0u, slot, k);
+      wave_lds_fence();
+#pragma unroll
+      for (int u = 0; u < U; ++u) xch[wv][2 * u + h][k] = v[u];
+      wave_lds_fence();
+      uint32_t *wide = a.out + (tile * per_iter + (size_t)wv * 4) * 128;  // four blocks of 128 = one wide block of 512
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int idx = j * 64 + lane;  // 16-byte piece of the wide block: row idx / 4, lane group idx % 4
+        stream_store(reinterpret_cast<u32x4 *>(wide + 4 * idx), xch[wv][idx & 3][idx >> 2]);
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const size_t blk = first + 2 * (size_t)u;
+        unpack_finish<B, MODE>(B != 0 ? ld[u] : u32x4{0, 0, 0, 0}, b[u], MODE != MODE_PLAIN ? seed[u] : 0u, slot, k,
+                               a.out + (((blk >> LS) * 128) << LS) + 4 * (blk & ((1u << LS) - 1)) + ((4 * (size_t)k) << LS));
+      }
     }
   }
 }
