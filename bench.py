@@ -19,37 +19,115 @@ Extra objects on the JSON line:
                 (512 + 16 b + 4 per block) / launch time from HIP events
                 recorded on the launch stream inside the timed region,
                 aggregated over the 32 widths, with the per-width table;
-  cpu_baseline  the reference's own simdunpackd1 (compiled from its sources
-                into oracle/_ref, SSE4.1) timed on this host on a bounded
-                sample, 1 thread (and all cores as `all_cores`);
-  encode        simdpackwithoutmaskd1 over the same corpus (rank 0's GPU, outside
-                the timed steps), output compared byte for byte with the payload;
+  cpu_baseline  the reference's own simdunpackd1 and simdpackwithoutmaskd1
+                (compiled from its sources into oracle/_ref, SSE4.1) timed on
+                this host over the first 2^26 docIDs of the SAME corpus the GPU
+                decodes (payload and offsets copied back), 1 thread and every
+                core this job may use; its output is compared with the GPU's;
+  encode        simdpackwithoutmaskd1 over the same corpus (outside the timed
+                steps), output compared byte for byte with the payload;
   callers       example.c's compress() and decode loop over the [width byte][payload]
                 stream as one device call each, and a batched simdsearchwithlengthd1,
                 on a mixed-width corpus; round trip and answers checked in place;
-  host_to_host  the same decode including pinned H2D/D2H copies.
-The legs beside the headline number (cpu_baseline, callers, host_to_host) run at
-N = 1 only.
+  host_to_host  the same decode including pinned H2D/D2H copies, at four uniform
+                widths and on a mixed-width (1..20 bits) corpus.
+`encode` and `host_to_host` run on every rank at the same time (each GPU has its
+own PCIe link; host memory is shared) and are reported per rank and summed;
+cpu_baseline and callers run at N = 1 only.
+
+Launching: under torch.distributed.run (RANK set) this process is one rank.
+Started plainly with --gpus N > 1 it is only a launcher: it touches no GPU, starts
+N child ranks of itself with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, relays
+rank 0's JSON line and exits non-zero if any rank does.  --selftest runs the
+launch, partition and verification all-reduce on CPU (gloo), without kernels.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from simdcomp_amd import binding, codec  # noqa: E402  (fails loudly if the HIP library is missing)
-
 HBM_PEAK = 8.0e12  # bytes/s, MI355X HBM3E nominal
 WIDTHS = list(range(1, 33))
 
+# set by load_package() in the ranks; the launcher never imports them
+np = torch = dist = binding = codec = None
 
+
+def load_package():
+    """numpy, torch and the ctypes front end of libsimdcomp_hip.so (fails loudly if the library is missing)."""
+    global np, torch, dist, binding, codec
+    import numpy
+    import torch as _torch
+    import torch.distributed as _dist
+
+    from simdcomp_amd import binding as b, codec as c
+
+    np, torch, dist, binding, codec = numpy, _torch, _dist, b, c
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` without torchrun
+# ---------------------------------------------------------------------------------------------------------------
+def launch_ranks(a, argv):
+    """Start a.gpus child ranks of this script (one per GPU) and wait for them.  This process initialises nothing
+    on the GPU.  Rank 0 prints the JSON line on our stdout; the other ranks' stdout goes to stderr."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    live = list(procs)
+    while live:
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                for q in live:  # a rank died: the others would wait in a barrier for ever
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
+
+
+def selftest(a, rank, world):
+    """The multi-rank plumbing without a GPU: gloo process group, block-range shards from the library's partitioner,
+    a host checksum per shard, and the verification all-reduce.  Rank 0 prints one JSON line."""
+    from simdcomp_amd import synth
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    assert dist.get_world_size() == a.gpus, (dist.get_world_size(), a.gpus)
+    total_blocks = world * 1001
+    first, nblocks = codec.partition(total_blocks, world, rank)
+    words = synth.rand_u32(5, total_blocks * 128)[first * 128:(first + nblocks) * 128]
+    idx = (np.arange(first * 128, (first + nblocks) * 128, dtype=np.uint64)) << np.uint64(32)
+    chk = int(synth.splitmix64(idx ^ words.astype(np.uint64)).sum(dtype=np.uint64))
+    acc = torch.tensor([chk >> 32, chk & 0xFFFFFFFF, first, nblocks], dtype=torch.int64)
+    dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        got = acc.tolist()
+        print(json.dumps({"selftest": True, "backend": "gloo", "n_gpus": dist.get_world_size(), "blocks": got[3],
+                          "sum_of_first": got[2], "checksum": ((got[0] << 32) + got[1]) & (2 ** 64 - 1)}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# corpus
+# ---------------------------------------------------------------------------------------------------------------
 def algorithmic_bytes(nblocks, b):
     """Bytes simdunpackd1 must move for nblocks blocks: payload read + output
     written + one 4-byte offset per block."""
@@ -80,6 +158,16 @@ def build_corpus(nblocks, b, seed, dev):
     acc = codec.checksum(back, other=ids)
     torch.cuda.synchronize()
     return payload, offsets, acc
+
+
+def gather_floats(x, distributed, dev):
+    """The value of every rank, in rank order."""
+    if not distributed:
+        return [float(x)]
+    t = torch.tensor([float(x)], dtype=torch.float64, device=dev)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
 
 
 def encode_leg(corpora, nblocks, seed0, dev, reps=3):
@@ -146,45 +234,98 @@ def measured_traffic(nblocks):
         return None
 
 
-def cpu_baseline(log2n=26, reps=3):
-    """The reference's simdunpackd1 on this host's cores (bounded sample)."""
+# ---------------------------------------------------------------------------------------------------------------
+# CPU baseline: the reference itself on this host, over the same corpus
+# ---------------------------------------------------------------------------------------------------------------
+def usable_cores():
+    """(cores this job may keep busy, how that was found).  os.cpu_count() is the whole machine; the scheduler
+    affinity and the cgroup CPU quota say what this job gets."""
+    nproc = os.cpu_count() or 1
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except Exception:
+        aff = nproc
+    quota = None
+    try:
+        f = open("/sys/fs/cgroup/cpu.max").read().split()
+        if f[0] != "max":
+            quota = max(1, int(int(f[0]) / int(f[1]) + 0.5))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            if q > 0:
+                quota = max(1, int(q / int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read()) + 0.5))
+        except Exception:
+            pass
+    n = min(aff, quota) if quota else aff
+    env = os.environ.get("OMP_NUM_THREADS")
+    if quota is None and env and env.isdigit() and int(env) < n:
+        n = int(env)  # no quota readable: the job's own thread budget
+    return max(1, n), {"nproc": nproc, "affinity": aff, "cgroup_quota": quota, "OMP_NUM_THREADS": env}
+
+
+def cpu_baseline(corpora, dev, log2n=26, reps=3):
+    """The reference's simdunpackd1 / simdpackwithoutmaskd1 on this host's cores over the first 2^log2n docIDs of
+    the corpus the GPU decodes (payload and per-block offsets copied back to host memory).  The checker side of the
+    same pass: the reference's decode of that sample is compared with the GPU's, and the reference's encode of the
+    decoded integers with the payload the GPU encoder produced."""
     try:
         import oracle
     except Exception as e:  # pragma: no cover
         return {"value": None, "unit": "int32/s", "cores": 0, "kind": "none", "sample": f"oracle unavailable: {e}"}
     orc = oracle.Oracle()
     if oracle.have_ref():
-        lib, kind, fn = oracle.Reference(), "reference", None
-        fn = lib._unpackd1
+        lib, kind = oracle.Reference(), "reference"
     else:
-        kind, fn = "port", orc._unpackd1
+        lib, kind = orc, "port"
     n = 1 << log2n
     nblk = n // 128
-    rng = np.random.default_rng(1)
+    ncores, how = usable_cores()
     out = np.empty(n, dtype=np.uint32)
-    seeds = rng.integers(0, 2 ** 32, nblk, dtype=np.uint32)
-    ncores = min(16, os.cpu_count() or 1)
-    t1 = tn = 0.0
+    t1 = tn = e1 = en = 0.0
+    dec_bad = enc_bad = 0
+    per_width = {}
+    nb = nblk
     for b in WIDTHS:
-        payload = rng.integers(0, 256, nblk * 16 * b, dtype=np.uint8)
-        t1 += orc.time_blocks(0, fn, seeds, payload, out, b, nblk, 1, reps)
-        tn += orc.time_blocks(0, fn, seeds, payload, out, b, nblk, ncores, reps)
-    total = n * len(WIDTHS)
+        payload_d, offsets_d = corpora[b]
+        nb = min(nblk, offsets_d.numel())
+        payload = payload_d[: nb * 16 * b].cpu().numpy()
+        seeds = offsets_d[:nb].cpu().numpy().view(np.uint32)
+        d1 = orc.time_blocks(0, lib._unpackd1, seeds, payload, out, b, nb, 1, reps)
+        dn = orc.time_blocks(0, lib._unpackd1, seeds, payload, out, b, nb, ncores, reps)
+        gpu = codec.unpackd1(offsets_d[:nb], payload_d, nb, b).cpu().numpy().view(np.uint32)
+        dec_bad += int((gpu != out[: nb * 128]).sum())
+        repacked = np.zeros_like(payload)
+        p1 = orc.time_blocks(2, lib._packwmd1, seeds, repacked, out, b, nb, 1, reps)
+        pn = orc.time_blocks(2, lib._packwmd1, seeds, repacked, out, b, nb, ncores, reps)
+        enc_bad += int((repacked != payload).sum())
+        t1, tn, e1, en = t1 + d1, tn + dn, e1 + p1, en + pn
+        per_width[str(b)] = {"decode_1": round(nb * 128 / d1 / 1e9, 2), "decode_all": round(nb * 128 / dn / 1e9, 2),
+                             "encode_1": round(nb * 128 / p1 / 1e9, 2), "encode_all": round(nb * 128 / pn / 1e9, 2)}
+        del gpu, payload, repacked
+    total = nb * 128 * len(WIDTHS)
     avx2 = None
     if kind == "reference" and oracle.have_ref_avx():
         # the reference's fastest CPU path for scale: avxunpack (8-lane format, no differential coding)
         ra = oracle.ReferenceAvx()
+        rng = np.random.default_rng(1)
         ta = 0.0
         for b in WIDTHS:
             payload = rng.integers(0, 256, nblk * 16 * b, dtype=np.uint8)
             ta += orc.time_blocks(4 + 1, ra.f[8][3], None, payload, out, b, nblk // 2, 1, reps)
-        avx2 = {"value": total / ta, "unit": "int32/s", "cores": 1, "what": "avxunpack (plain, 256-integer blocks)"}
-    callers = cpu_callers(orc, lib if kind == "reference" else orc)
+        avx2 = {"value": n * len(WIDTHS) / ta, "unit": "int32/s", "cores": 1, "what": "avxunpack (plain, 256-integer blocks), random payload"}
+    callers = cpu_callers(orc, lib)
+    built = ("oracle/_ref built -O3 -msse4.1 (the reference's Makefile says -march=native; SSE4.1 so that one build "
+             "runs on any host)") if kind == "reference" else "scalar restatement"
     return {"value": total / t1, "unit": "int32/s", "cores": 1, "kind": kind, "callers": callers,
             "stock_benchmark": stock_benchmark(), "cpu_model": cpu_model(),
-            "sample": f"simdunpackd1 over 2^{log2n} ints (out of cache) at each b=1..32, best of {reps}, "
-                      f"{'oracle/_ref built -O3 -msse4.1' if kind == 'reference' else 'scalar restatement'}",
-            "all_cores": {"value": total / tn, "cores": ncores}, "avx2_comparator": avx2}
+            "sample": f"simdunpackd1 over the first 2^{log2n} docIDs of the GPU's own corpus (payload + offsets copied to the "
+                      f"host, out of cache) at each b=1..32, best of {reps}, {built}",
+            "all_cores": {"value": total / tn, "cores": ncores, "how_counted": how},
+            "encode": {"what": "simdpackwithoutmaskd1 over the integers just decoded", "value": total / e1, "cores": 1,
+                       "all_cores": {"value": total / en, "cores": ncores}},
+            "decode_vs_gpu_mismatches": dec_bad, "encode_vs_gpu_payload_mismatches": enc_bad,
+            "blocks_compared_per_width": nb, "per_width_Gint/s": per_width, "avx2_comparator": avx2}
 
 
 def cpu_model():
@@ -201,9 +342,7 @@ def stock_benchmark():
     """The reference's own benchmarks/bitpackingbenchmark.c (one 128-integer block in cache, best of 500 calls, cycles
     per integer including its rdtsc/cpuid bracket), linked with the reference's own routines: oracle/_ref/
     bitpackingbenchmark_ref.  Mean over b=1..32 of each column; None when the binary was not built."""
-    import subprocess
-
-    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle", "_ref", "bitpackingbenchmark_ref")
+    exe = os.path.join(ROOT, "oracle", "_ref", "bitpackingbenchmark_ref")
     if not os.path.exists(exe):
         return None
     try:
@@ -224,7 +363,7 @@ def stock_benchmark():
             for k, v in res.items() if v}
 
 
-def cpu_callers(orc, codec, log2n=24):
+def cpu_callers(orc, block_codec, log2n=24):
     """The callers either side of the block codec on one host core, same bounded-sample idea: the decode loop of
     example.c:101-110 over a [width byte][payload] stream, and simdsearchwithlengthd1 once per (random block, key)."""
     from simdcomp_amd import synth
@@ -234,11 +373,11 @@ def cpu_callers(orc, codec, log2n=24):
     gaps = synth.rand_u32(12, nblk * 128).reshape(nblk, 128)
     gaps &= ((np.uint64(1) << widths.astype(np.uint64)) - np.uint64(1)).astype(np.uint32)[:, None]
     ids = (np.cumsum(gaps.reshape(-1).astype(np.uint64)) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
-    stream = orc.stream_compress(ids, d1=True, codec=codec)
+    stream = orc.stream_compress(ids, d1=True, codec=block_codec)
     best = 1e9
     for _ in range(3):
         t0 = time.perf_counter()
-        dec = orc.stream_decode(stream, nblk, d1=True, codec=codec)
+        dec = orc.stream_decode(stream, nblk, d1=True, codec=block_codec)
         best = min(best, time.perf_counter() - t0)
     ok = bool(np.array_equal(dec, ids))
     n, bits, off, status = orc.stream_walk(stream, nblk)
@@ -247,10 +386,24 @@ def cpu_callers(orc, codec, log2n=24):
     qb = (synth.rand_u32(13, nq) % np.uint32(nblk)).astype(np.uint64)
     keys = (ids.reshape(nblk, 128)[qb.astype(np.int64), synth.rand_u32(14, nq) % np.uint32(128)] + np.uint32(1)).astype(np.uint32)
     pay = np.concatenate([stream, np.zeros(512, np.uint8)])
-    ts, pos, val = orc.time_search(seeds, pay, off + np.arange(nblk, dtype=np.uint64) + np.uint64(1), bits, qb, keys, codec=codec)
+    ts, pos, val = orc.time_search(seeds, pay, off + np.arange(nblk, dtype=np.uint64) + np.uint64(1), bits, qb, keys, codec=block_codec)
     return {"stream_decode_int32/s": nblk * 128 / best, "stream_decode_ok": ok and status == 0 and n == nblk,
             "search_queries/s": nq / ts, "cores": 1,
             "sample": f"2^{log2n} docIDs, widths 1..20; 2^20 searches with a random block each"}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# callers on the device
+# ---------------------------------------------------------------------------------------------------------------
+def mixed_ids(n, dev, seed, lo=0, hi=20):
+    """Sorted docIDs whose blocks need lo..hi bits for their gaps, skewed small (minimum of two uniform draws)."""
+    nblk = n // 128
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    w = torch.minimum(torch.randint(lo, hi + 1, (nblk,), device=dev, generator=g), torch.randint(lo, hi + 1, (nblk,), device=dev, generator=g))
+    gaps = torch.randint(0, 1 << 30, (n,), dtype=torch.int32, device=dev, generator=g)
+    gaps &= ((1 << w) - 1).to(torch.int32).repeat_interleave(128)
+    return torch.cumsum(gaps, 0, dtype=torch.int32), g
 
 
 def callers_leg(dev, log2n):
@@ -262,13 +415,7 @@ def callers_leg(dev, log2n):
     st = torch.cuda.current_stream().cuda_stream
     n = 1 << log2n
     nblk = n // 128
-    g = torch.Generator(device=dev)
-    g.manual_seed(77)
-    w = torch.minimum(torch.randint(0, 21, (nblk,), device=dev, generator=g), torch.randint(0, 21, (nblk,), device=dev, generator=g))
-    gaps = torch.randint(0, 1 << 30, (n,), dtype=torch.int32, device=dev, generator=g)
-    gaps &= ((1 << w) - 1).to(torch.int32).repeat_interleave(128)
-    ids = torch.cumsum(gaps, 0, dtype=torch.int32)
-    del gaps, w
+    ids, g = mixed_ids(n, dev, 77)
 
     def best(f, reps=5):
         f()
@@ -324,21 +471,39 @@ def callers_leg(dev, log2n):
             "search": {"queries": nq, "ms": round(t_s * 1e3, 4), "queries/s": nq / t_s, "answers_ok": search_ok}}
 
 
-def host_to_host(dev, log2n=28, widths=(1, 8, 16, 32)):
-    """Decode that starts and ends in pinned host memory: H2D payload+offsets,
-    kernel, D2H integers, pipelined in 2^24-integer pieces over two streams."""
+# ---------------------------------------------------------------------------------------------------------------
+# host to host
+# ---------------------------------------------------------------------------------------------------------------
+def host_to_host(dev, barrier, distributed, log2n=28, widths=(1, 8, 16, 32)):
+    """Decode that starts and ends in pinned host memory: H2D payload (+ offsets, widths), kernel, D2H integers,
+    pipelined in 2^24-integer pieces over two streams.  Every rank runs it on its own GPU at the same time (a barrier
+    in front of every timed pass): `per_rank` lists each rank's rate, `aggregate` their sum.  The `mixed` case is the
+    per-block-width d1 corpus of BASELINE configs[4] (widths 1..20): widths, payload offsets and seeds travel with
+    the payload, and simdcomp_hip_unpack_mixed decodes a piece."""
     n = 1 << log2n
     nblk = n // 128
     piece = 1 << 17  # blocks per piece (2^24 integers)
-    res = {}
     streams = [torch.cuda.Stream(), torch.cuda.Stream()]
     h_out = torch.empty(n, dtype=torch.int32, pin_memory=True)
+    L, P = binding.lib(), binding.ptr
+
+    def timed(run):
+        run()
+        best = 1e9
+        for _ in range(3):
+            barrier()
+            t0 = time.perf_counter()
+            run()
+            best = min(best, time.perf_counter() - t0)
+        return best
+
+    res = {}
     h_off = torch.empty(nblk, dtype=torch.int32, pin_memory=True).fill_(12345)
+    d_out = [torch.empty(piece * 128, dtype=torch.int32, device=dev) for _ in range(2)]
     for b in widths:
         h_pay = torch.empty(nblk * 16 * b, dtype=torch.uint8, pin_memory=True).fill_(0x5B)
         d_pay = [torch.empty(piece * 16 * b, dtype=torch.uint8, device=dev) for _ in range(2)]
         d_off = [torch.empty(piece, dtype=torch.int32, device=dev) for _ in range(2)]
-        d_out = [torch.empty(piece * 128, dtype=torch.int32, device=dev) for _ in range(2)]
 
         def run():
             for i, first in enumerate(range(0, nblk, piece)):
@@ -351,17 +516,63 @@ def host_to_host(dev, log2n=28, widths=(1, 8, 16, 32)):
                     h_out[first * 128:(first + cnt) * 128].copy_(d_out[s][: cnt * 128], non_blocking=True)
             torch.cuda.synchronize()
 
-        run()
-        best = 1e9
-        for _ in range(3):
-            t0 = time.perf_counter()
-            run()
-            best = min(best, time.perf_counter() - t0)
-        res[str(b)] = {"Gint/s": round(n / best / 1e9, 2), "GB/s_over_pcie": round((n * 4 + nblk * (16 * b + 4)) / best / 1e9, 1)}
-        del h_pay, d_pay
-    return {"ints": n, "pinned": True, "per_width": res}
+        best = timed(run)
+        rates = gather_floats(n / best, distributed, dev)
+        pcie = n * 4 + nblk * (16 * b + 4)
+        res[str(b)] = {"Gint/s": round(sum(rates) / 1e9, 2), "GB/s_over_pcie": round(sum(rates) / n * pcie / 1e9, 1),
+                       "per_rank_Gint/s": [round(r / 1e9, 2) for r in rates]}
+        del h_pay, d_pay, d_off
+
+    # mixed widths: build the corpus on the device, keep it in pinned host memory the way an index file would be
+    ids, _ = mixed_ids(n, dev, 79, 1, 20)
+    seeds_d = torch.empty(nblk, dtype=torch.int32, device=dev)
+    bits_d = codec.maxbitsd1(ids, initvalue=0, initvalues_out=seeds_d)
+    off_d, total_d = codec.payload_offsets(bits_d)
+    total = int(total_d.item())
+    arena = torch.empty(total + 16, dtype=torch.uint8, device=dev)
+    codec.pack_mixed(1, ids, bits_d, off_d, arena, initvalues=seeds_d, masked=False)
+    h_ids = ids.cpu()
+    h_pay = torch.empty(total + 16, dtype=torch.uint8, pin_memory=True).copy_(arena)
+    h_bits = torch.empty(nblk, dtype=torch.uint8, pin_memory=True).copy_(bits_d)
+    h_offs = torch.empty(nblk, dtype=torch.int64, pin_memory=True).copy_(off_d)
+    h_seeds = torch.empty(nblk, dtype=torch.int32, pin_memory=True).copy_(seeds_d)
+    del ids, arena, bits_d, off_d, seeds_d
+    firsts = list(range(0, nblk, piece))
+    lo = [int(h_offs[f]) for f in firsts]
+    hi = lo[1:] + [total]
+    cap = max(h - l for l, h in zip(lo, hi))
+    d_pay = [torch.empty(cap + 16, dtype=torch.uint8, device=dev) for _ in range(2)]
+    d_bits = [torch.empty(piece, dtype=torch.uint8, device=dev) for _ in range(2)]
+    d_offs = [torch.empty(piece, dtype=torch.int64, device=dev) for _ in range(2)]
+    d_seeds = [torch.empty(piece, dtype=torch.int32, device=dev) for _ in range(2)]
+
+    def run_mixed():
+        for i, first in enumerate(firsts):
+            s = i & 1
+            with torch.cuda.stream(streams[s]):
+                cnt = min(piece, nblk - first)
+                d_pay[s][: hi[i] - lo[i]].copy_(h_pay[lo[i]:hi[i]], non_blocking=True)
+                d_bits[s][:cnt].copy_(h_bits[first:first + cnt], non_blocking=True)
+                d_offs[s][:cnt].copy_(h_offs[first:first + cnt], non_blocking=True)
+                d_seeds[s][:cnt].copy_(h_seeds[first:first + cnt], non_blocking=True)
+                # the offsets are those of the whole arena: the piece's payload pointer is moved back by the
+                # offset of its first block
+                binding.check(L.simdcomp_hip_unpack_mixed(1, P(d_seeds[s]), d_pay[s].data_ptr() - lo[i], P(d_offs[s]), P(d_bits[s]),
+                                                          P(d_out[s]), cnt, torch.cuda.current_stream().cuda_stream), "unpack_mixed")
+                h_out[first * 128:(first + cnt) * 128].copy_(d_out[s][: cnt * 128], non_blocking=True)
+        torch.cuda.synchronize()
+
+    best = timed(run_mixed)
+    ok = bool(torch.equal(h_out, h_ids))
+    rates = gather_floats(n / best, distributed, dev)
+    pcie = n * 4 + total + nblk * 13
+    res["mixed"] = {"Gint/s": round(sum(rates) / 1e9, 2), "GB/s_over_pcie": round(sum(rates) / n * pcie / 1e9, 1),
+                    "per_rank_Gint/s": [round(r / 1e9, 2) for r in rates], "bits_per_int": round(total * 8 / n, 2),
+                    "round_trip_ok": ok, "what": "d1, per-block widths 1..20 (BASELINE configs[4] shape), simdcomp_hip_unpack_mixed"}
+    return {"ints_per_rank": n, "pinned": True, "ranks": len(rates), "per_width": res}
 
 
+# ---------------------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -372,20 +583,32 @@ def main():
     ap.add_argument("--no-h2h", action="store_true", help="skip the host-to-host leg")
     ap.add_argument("--no-encode", action="store_true", help="skip the encoder leg")
     ap.add_argument("--no-callers", action="store_true", help="skip the stream / search leg")
+    ap.add_argument("--selftest", action="store_true", help="CPU-only check of the multi-rank plumbing (gloo)")
     a = ap.parse_args()
 
+    if "RANK" not in os.environ and a.gpus > 1:
+        # plain `python bench.py --gpus N`: become the launcher (nothing below runs in this process)
+        sys.exit(launch_ranks(a, sys.argv[1:]))
+
+    load_package()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        sys.exit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE is {world}")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    if a.selftest:
+        return selftest(a, rank, world)
+
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # under torch.distributed.run (RANK set) the process group is always created, also for one rank, so that the
     # same code path runs at every N
     distributed = world > 1 or "RANK" in os.environ
     if distributed:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        assert dist.get_world_size() == a.gpus, (dist.get_world_size(), a.gpus)
 
     # block-range shard of the global corpus (weak scaling: 2^log2n docIDs per GPU)
     total_blocks = world * ((1 << a.log2n) // 128)
@@ -445,15 +668,21 @@ def main():
         tot_time += avg
         table[str(b)] = {"ms": round(avg * 1e3, 4), "GB/s": round(nbytes / avg / 1e9, 1),
                          "frac": round(nbytes / avg / HBM_PEAK, 4), "Gint/s": round(nblocks * 128 / avg / 1e9, 1)}
+    rank_fracs = gather_floats(tot_bytes / tot_time / HBM_PEAK, distributed, dev)
 
+    line = None
     if rank == 0:
         ints_per_step = world * nblocks * 128 * len(WIDTHS)
         achieved = tot_bytes / tot_time
+        if "TORCHELASTIC_RUN_ID" in os.environ:
+            how = "torch.distributed.run"
+        else:
+            how = "bench.py launcher, one child process per GPU" if distributed else "single process"
         line = {
             "metric": "device-resident decoded int32/s (simdunpackd1, b=1..32)",
             "value": ints_per_step * a.steps / elapsed,
             "unit": "int32/s",
-            "n_gpus": world,
+            "n_gpus": dist.get_world_size() if distributed else 1,
             "steps": a.steps,
             "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3,
@@ -465,35 +694,52 @@ def main():
             "config": {"workload": "BASELINE configs[2]: sorted posting lists, 2^%d docIDs per GPU, random gaps < 2^b, "
                                    "simdunpackd1 with stored per-block offsets, one launch per width b=1..32 per step"
                                    % a.log2n,
-                       "ints_per_gpu": nblocks * 128, "widths": "1..32", "sharding": "block range, no data-path collective"},
+                       "ints_per_gpu": nblocks * 128, "widths": "1..32", "sharding": "block range, no data-path collective",
+                       "launch": how},
             "verification": {"decode_mismatches": int(verify[1].item()), "checksum": int(verify[0].item()) & (2 ** 64 - 1)},
             "roofline": {"bound": "hbm", "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK, 4), "traffic": measured_traffic(nblocks),
                          "algorithmic_bytes_per_launch": tot_bytes / len(WIDTHS),
-                         "traffic_note": "L2<->fabric bytes from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
-                                         "(reads = 2 x FETCH_SIZE on gfx950); widths 1..7 fetch their payload twice at this "
-                                         "level (prefetch workgroup + decode workgroup, second copy from the Infinity Cache), "
-                                         "widths >= 8 are within 4 % of algorithmic",
+                         "traffic_source": "profiles/pmc_traffic_latest.json: an earlier rocprofv3 --pmc run of this same "
+                                           "command (separate FETCH_SIZE / WRITE_SIZE passes), not measured in this run",
+                         "traffic_note": "L2<->fabric bytes (reads = 2 x FETCH_SIZE on gfx950); widths 1..7 fetch their "
+                                         "payload twice at this level (prefetch workgroup + decode workgroup, second copy "
+                                         "from the Infinity Cache), widths >= 8 are within 4 % of algorithmic",
                          "kernel": "sc::k_unpack_fast<b, d1> (one instantiation per width), aggregate over b=1..32",
                          "bytes_per_block": "512 + 16*b + 4",
                          "min_frac": min(v["frac"] for v in table.values()),
+                         "per_rank_frac": [round(f, 4) for f in rank_fracs],
                          "per_width": table},
         }
         line["roofline"]["measured_ceilings"] = ceilings(out)
-        if not a.no_encode:
-            del out
-            line["encode"] = encode_leg(corpora, nblocks, seed0, dev)
-        # the legs beside the headline number run at N = 1 only: at N > 1 the other ranks would sit in the final
-        # barrier while rank 0 works
-        if not a.no_cpu and world == 1:
-            line["cpu_baseline"] = cpu_baseline()
-        del corpora
+    del out
+    if not a.no_encode:
+        barrier()
+        enc = encode_leg(corpora, nblocks, seed0, dev)
+        vals = gather_floats(enc["value"], distributed, dev)
+        wrong = gather_floats(enc["widths_with_wrong_bytes"], distributed, dev)
+        if rank == 0:
+            enc["per_rank_value"] = vals
+            enc["aggregate_value"] = sum(vals)
+            enc["aggregate_unit"] = "int32/s over all GPUs"
+            enc["widths_with_wrong_bytes"] = int(sum(wrong))
+            line["encode"] = enc
+    # cpu_baseline and callers run at N = 1 only: at N > 1 the other ranks would sit in a barrier while rank 0 works
+    if rank == 0 and not a.no_cpu and world == 1:
+        cb = cpu_baseline(corpora, dev)
+        line["cpu_baseline"] = cb
+        line["verification"]["sampled_blocks_vs_oracle_mismatches"] = cb.get("decode_vs_gpu_mismatches")
+        line["verification"]["sampled_blocks_per_width"] = cb.get("blocks_compared_per_width")
+    del corpora
+    torch.cuda.empty_cache()
+    if rank == 0 and not a.no_callers and world == 1:
+        line["callers"] = callers_leg(dev, a.log2n)
         torch.cuda.empty_cache()
-        if not a.no_callers and world == 1:
-            line["callers"] = callers_leg(dev, a.log2n)
-            torch.cuda.empty_cache()
-        if not a.no_h2h and world == 1:
-            line["host_to_host"] = host_to_host(dev)
+    if not a.no_h2h:
+        h2h = host_to_host(dev, barrier, distributed)
+        if rank == 0:
+            line["host_to_host"] = h2h
+    if rank == 0:
         print(json.dumps(line), flush=True)
     if distributed:
         dist.barrier()

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void k_unpack_flex(UnpackArgs a) {
       if constexpr (B >= 0) {
         b[u] = B;
       } else {
-        b[u] = a.bits ? (valid[u] ? wb : 0u) : a.bit;
+        b[u] = a.bits ? (valid[u] ? (wb > 32 ? 32u : wb) : 0u) : a.bit;  // a width byte above 32 counts as 32
       }
       const uint64_t has_off = a.off ? ~0ull : 0ull;
       const uint64_t by_off = po + (a.stream_layout ? a.block_base + bc + 1 : 0);
@@ -198,6 +198,7 @@ __global__ __launch_bounds__(256) void k_pack_flex(PackArgs a) {
         b[u] = B;
       } else {
         b[u] = a.bits ? (valid[u] ? a.bits[blk[u]] : 0u) : a.bit;
+        b[u] = b[u] > 32 ? 32 : b[u];  // a width byte above 32 counts as 32
       }
     }
 #pragma unroll
@@ -495,10 +496,11 @@ __global__ __launch_bounds__(BS) void k_unpack_fast(UnpackArgs a, uint32_t nwg =
       uint64_t o[U];
       constexpr int NB = 2 * U;
       const size_t mine = tile * per_iter + (size_t)wv * NB + (size_t)(lane % NB);
-      const uint32_t mb = a.bits[mine];
+      const uint32_t mb_raw = a.bits[mine];
       const uint64_t mo = a.off[mine];
       uint32_t ms = 0;
       if constexpr (MODE != MODE_PLAIN) ms = a.seeds[mine];
+      const uint32_t mb = mb_raw > 32 ? 32 : mb_raw;  // a width byte above 32 is treated as 32 (nothing is indexed with it)
       hand_out<U>(mb, h, b);
       hand_out<U>(mo, h, o);
       if constexpr (MODE != MODE_PLAIN) hand_out<U>(ms, h, seed);
@@ -621,6 +623,7 @@ __global__ __launch_bounds__(BS) void k_pack_fast(PackArgs a) {
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
+      if constexpr (B < 0) b[u] = b[u] > 32 ? 32 : b[u];  // as in the decoder: a width byte above 32 counts as 32
       if constexpr (MODE == MODE_D1) {
         const bool start = first + 2 * (size_t)u == 0 && a.chain_base == 0;
         seed[u] = (!a.seeds && start) ? a.seed0 : seed[u];

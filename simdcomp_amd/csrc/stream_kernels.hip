@@ -548,8 +548,10 @@ __global__ __launch_bounds__(EMIT_THREADS) void k_index_emit(const uint8_t *stre
     for (int i = 0; i < BATCH; ++i) {
       if (ok && p < end) {
         const uint32_t b = stream[p];
-        if (b > 32) {
-          ok = false;  // the spine has already reported the stream as bad
+        if (b > 32 || p + 1 + 16 * (size_t)b > nbytes) {
+          // a bad width byte, or a record that runs past the end of the stream: the spine has already reported the
+          // stream as bad; nothing is written for it, so that no later kernel reads a payload beyond the stream
+          ok = false;
         } else {
           ps[i] = p;
           bs[i] = b;

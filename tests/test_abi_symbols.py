@@ -34,6 +34,18 @@ def test_library_exports_every_declared_symbol():
     assert sorted(binding.HOST_API) == host
 
 
+def test_library_exports_nothing_else():
+    """The dynamic symbol table holds the declared functions and nothing more: no helper of the library can collide
+    with, or be interposed by, a symbol of the program that loads it (the reference's export list is just as closed,
+    simdcomp.def.tpl:1-40)."""
+    import subprocess
+
+    out = subprocess.run(["nm", "-D", "--defined-only", binding.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted(line.split()[-1].split("@")[0] for line in out.splitlines() if line.strip())
+    declared = sorted(set(declared_functions("simdcomp_hip.h") + declared_functions("simdcomp.h")))
+    assert exported == declared, (sorted(set(exported) - set(declared)), sorted(set(declared) - set(exported)))
+
+
 def test_version_and_sizes(orc):
     lib = binding.lib()
     assert lib.simdcomp_hip_version() >= 100

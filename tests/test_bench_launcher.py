@@ -1,0 +1,56 @@
+"""`python bench.py --gpus N` with no torchrun around it must start N ranks itself.  --selftest runs that launcher end
+to end on CPU: N child processes, a gloo process group, block-range shards from the library's partitioner, and the
+verification all-reduce, without any kernel."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from simdcomp_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+M64 = (1 << 64) - 1
+
+
+def run_selftest(gpus, env_extra=None, args=()):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--selftest", *args],
+                          capture_output=True, text=True, timeout=300, env=env)
+
+
+def whole_checksum(total_blocks):
+    words = synth.rand_u32(5, total_blocks * 128)
+    idx = np.arange(total_blocks * 128, dtype=np.uint64) << np.uint64(32)
+    return int(synth.splitmix64(idx ^ words.astype(np.uint64)).sum(dtype=np.uint64)) & M64
+
+
+@pytest.mark.parametrize("gpus", [1, 2, 3])
+def test_launcher_starts_n_ranks(gpus):
+    out = run_selftest(gpus)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout  # only rank 0 prints on stdout
+    doc = json.loads(lines[0])
+    assert doc["n_gpus"] == gpus and doc["backend"] == "gloo"
+    assert doc["blocks"] == gpus * 1001
+    # shards are contiguous and equal: firsts are 0, 1001, 2002, ...
+    assert doc["sum_of_first"] == 1001 * gpus * (gpus - 1) // 2
+    assert doc["checksum"] == whole_checksum(gpus * 1001)
+
+
+def test_world_size_must_match_gpus():
+    """Under a launcher that set WORLD_SIZE (torch.distributed.run), --gpus has to agree with it."""
+    out = run_selftest(2, env_extra={"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_PORT": "29533"})
+    assert out.returncode != 0 and "WORLD_SIZE" in out.stderr
+
+
+def test_failing_rank_fails_the_launch():
+    """Ranks that die take the launch down with a non-zero exit code; and a missing HIP library is fatal (there is
+    no other implementation to fall back to)."""
+    out = run_selftest(2, env_extra={"SIMDCOMP_HIP_LIB": "/nonexistent/libsimdcomp_hip.so"})
+    assert out.returncode != 0
+    assert "not found" in out.stderr
