@@ -155,6 +155,41 @@ def test_index_rejects_bad_streams(dev, orc):
     assert dev.stream_index(torch.empty(0, dtype=torch.uint8, device="cuda"), 4)[2].tolist() == [0, 0, 0]
 
 
+@pytest.mark.parametrize("d1", [True, False])
+def test_decode_of_truncated_streams_reads_no_record_past_the_end(dev, orc, d1):
+    """simdcomp_hip_stream_decode on streams that end inside their last record (one byte short; a last width byte of
+    32 with nothing behind it): reported in d_result[2], the cut record is not indexed (its width stays 0 in the
+    workspace, so no kernel reads a payload that lies beyond the stream), and the records in front decode as before."""
+    import torch
+
+    from simdcomp_amd import binding as B
+
+    L = B.lib()
+    nblk = 700
+    x = G.stream_corpus(55, nblk)
+    s = orc.stream_compress(x, d1=d1)
+    n, bits, off, _ = orc.stream_walk(s, nblk)
+    last = int(off[nblk - 1]) + nblk - 1  # position of the last record's width byte
+    want = orc.stream_decode(s, nblk, d1=d1)
+    cases = [s[:-1]] if bits[nblk - 1] else []
+    cases.append(np.concatenate([s[:last], [32]]).astype(np.uint8))           # width byte 32, no payload at all
+    cases.append(np.concatenate([s[:last], [32], np.full(511, 0xEE)]).astype(np.uint8))  # one byte short of a 32-bit record
+    for bad in cases:
+        T = bad.size
+        # the stream ends exactly at the end of its buffer; what follows in memory is another tensor full of 0xFF
+        d = to_dev(bad)
+        out = torch.zeros(nblk * 128, dtype=torch.int32, device="cuda")
+        res = torch.zeros(3, dtype=torch.int64, device="cuda")
+        ws = torch.full((max(16, L.simdcomp_hip_stream_decode_workspace(T, nblk)),), 0xFF, dtype=torch.uint8, device="cuda")
+        B.check(L.simdcomp_hip_stream_decode(D1 if d1 else PLAIN, 0, B.ptr(d), T, nblk, B.ptr(out), B.ptr(res), B.ptr(ws),
+                                             torch.cuda.current_stream().cuda_stream), "stream_decode")
+        torch.cuda.synchronize()
+        assert res.tolist()[2] == 1
+        got_bits = ws[:nblk].cpu().numpy()
+        assert np.array_equal(got_bits[: nblk - 1], bits[: nblk - 1]) and got_bits[nblk - 1] == 0
+        assert np.array_equal(u32(out)[: (nblk - 1) * 128], want[: (nblk - 1) * 128])
+
+
 def test_index_dense_and_sparse_records(dev, orc):
     """All-zero widths (one record per byte: tens of thousands of records per index chunk) and all-32 widths."""
     import torch
