@@ -119,6 +119,22 @@ size_t simdcomp_hip_payload_offsets_workspace(size_t nblocks);
 int simdcomp_hip_payload_offsets(const uint8_t *d_bits, size_t nblocks, uint64_t *d_payload_offsets,
                                  uint64_t *d_total_bytes, void *d_workspace, void *stream);
 
+/* simdcomp_hip_payload_offsets for callers that cannot allocate device memory or
+ * carry a workspace (code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc).  No counterpart in the reference, which never
+ * allocates (it has no scan: its callers advance a pointer, example.c:72).  Same
+ * kernels and same results as simdcomp_hip_payload_offsets; the scan's tile sums
+ * go to a 1 MiB device array that belongs to the library (one copy per GPU, held
+ * until the process ends), so the call performs no hipMalloc / hipFree.  Its
+ * device address is resolved on the first call on each device (make that call
+ * outside graph capture).  Limit: nblocks <=
+ * simdcomp_hip_payload_offsets_noalloc_max_blocks() (2^29 blocks = 2^36
+ * integers), beyond that SIMDCOMP_HIP_ESIZE.  Calls on the same GPU share the
+ * array: two of them in flight at once (different streams or threads) race. */
+size_t simdcomp_hip_payload_offsets_noalloc_max_blocks(void);
+int simdcomp_hip_payload_offsets_noalloc(const uint8_t *d_bits, size_t nblocks, uint64_t *d_payload_offsets,
+                                         uint64_t *d_total_bytes, void *stream);
+
 /* ---- arbitrary lengths (device-resident forms of the *_length routines) ---- */
 
 /* simdpack_compressedbytes / simdpackFOR_compressedbytes

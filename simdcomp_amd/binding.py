@@ -32,6 +32,8 @@ DEVICE_API = {
     "simdcomp_hip_reduce_length": (C.c_int, [vp, sz, u32, vp, vp]),
     "simdcomp_hip_payload_offsets_workspace": (sz, [sz]),
     "simdcomp_hip_payload_offsets": (C.c_int, [vp, sz, vp, vp, vp, vp]),
+    "simdcomp_hip_payload_offsets_noalloc_max_blocks": (sz, []),
+    "simdcomp_hip_payload_offsets_noalloc": (C.c_int, [vp, sz, vp, vp, vp]),
     "simdcomp_hip_chain_workspace": (sz, [sz]),
     "simdcomp_hip_chain_offsets": (C.c_int, [u32, vp, vp, vp, sz, C.c_int, vp, vp, vp]),
     "simdcomp_hip_pack_stream": (C.c_int, [C.c_int, C.c_int, u32, vp, vp, vp, vp, vp, sz, vp, vp]),

@@ -5,6 +5,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
+
 #include "../../include/simdcomp_hip.h"
 #include "codec_kernels.h"
 #include "stream_kernels.h"
@@ -215,6 +217,55 @@ int simdcomp_hip_payload_offsets(const uint8_t *d_bits, size_t nblocks, uint64_t
   if (nblocks && (!d_bits || !d_payload_offsets || !d_workspace)) return fail(SIMDCOMP_HIP_ENULL, "NULL pointer");
   return hip_result(sc::launch_payload_offsets(d_bits, nblocks, d_payload_offsets, d_total_bytes, d_workspace,
                                                as_stream(stream)),
+                    "payload offsets launch");
+}
+
+// ---- the offsets scan for callers that cannot allocate ------------------------------------------------------------
+// Same kernels as simdcomp_hip_payload_offsets; their tile sums (8 bytes per 4096 blocks) live in a device array of
+// this library instead of a caller's workspace.  The array's name is only a host-side handle: its device address is
+// looked up once per device (hipGetSymbolAddress, with that device current) and that address is what the kernels get.
+namespace {
+constexpr size_t SCRATCH_BYTES = (size_t)1 << 20;
+constexpr int SCRATCH_MAX_DEVICES = 64;
+__device__ __align__(256) unsigned char scratch[SCRATCH_BYTES];
+std::atomic<void *> g_scratch_ptr[SCRATCH_MAX_DEVICES];
+
+// Device address of `scratch` on the current device (every GPU holds its own copy at its own address).
+int scratch_on_current_device(void **out) {
+  int dev = -1;
+  if (hipError_t e = hipGetDevice(&dev)) return hip_result(e, "hipGetDevice");
+  if (dev < 0 || dev >= SCRATCH_MAX_DEVICES) return fail(SIMDCOMP_HIP_ESIZE, "device ordinal beyond the scratch table");
+  void *p = g_scratch_ptr[dev].load(std::memory_order_acquire);
+  if (!p) {
+    if (hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch))) return hip_result(e, "hipGetSymbolAddress(scratch)");
+    if (!p) return fail(SIMDCOMP_HIP_ENULL, "hipGetSymbolAddress returned no address for the scratch array");
+    g_scratch_ptr[dev].store(p, std::memory_order_release);  // threads racing here store the same address
+  }
+  *out = p;
+  return SIMDCOMP_HIP_OK;
+}
+}  // namespace
+
+size_t simdcomp_hip_payload_offsets_noalloc_max_blocks(void) {
+  // scan_workspace_bytes(n) = 8 bytes per 4096 blocks
+  size_t lo = 0, hi = (size_t)1 << 40;
+  while (lo < hi) {
+    const size_t mid = lo + (hi - lo + 1) / 2;
+    if (sc::scan_workspace_bytes(mid) <= SCRATCH_BYTES) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+int simdcomp_hip_payload_offsets_noalloc(const uint8_t *d_bits, size_t nblocks, uint64_t *d_payload_offsets,
+                                         uint64_t *d_total_bytes, void *stream) {
+  if (nblocks && (!d_bits || !d_payload_offsets)) return fail(SIMDCOMP_HIP_ENULL, "NULL pointer");
+  if (sc::scan_workspace_bytes(nblocks) > SCRATCH_BYTES)
+    return fail(SIMDCOMP_HIP_ESIZE, "nblocks beyond simdcomp_hip_payload_offsets_noalloc_max_blocks(): use "
+                                    "simdcomp_hip_payload_offsets with a workspace");
+  void *ws = nullptr;
+  if (int rc = scratch_on_current_device(&ws)) return rc;
+  // nothing in the scratch has to start at zero: the first kernel writes every tile sum the later ones read
+  return hip_result(sc::launch_payload_offsets(d_bits, nblocks, d_payload_offsets, d_total_bytes, ws, as_stream(stream)),
                     "payload offsets launch");
 }
 
