@@ -12,10 +12,19 @@
  * *_length routines here (pipelined in 64 MiB pieces) or, better, keep data on
  * the device and call the batched entry points of simdcomp_hip.h.
  *
+ * Threads: as in the reference (stateless, src/simdbitpacking.c:14379-14399),
+ * any number of threads may call at the same time on disjoint buffers; every
+ * calling thread works with streams and staging buffers of its own.
+ * Devices: a call runs on the HIP device that is current in the calling thread
+ * and leaves that selection untouched.  With SIMDCOMP_HIP_DEVICES=0,1,... in
+ * the environment the calling threads are spread over the listed GPUs instead
+ * (first thread -> first entry, and so on, round robin).
+ *
  * Differences a caller can observe, all outside the reference's contract:
- *   - if no usable GPU is present, or a HIP call fails, the routine prints the
- *     HIP error to stderr and aborts (the reference API has no error channel);
- *   - calls are serialised on an internal lock (the reference is re-entrant);
+ *   - if no usable GPU is present, or a HIP call fails, the routine calls the
+ *     handler set with simdcomp_hip_set_error_handler (simdcomp_hip.h) or, by
+ *     default, prints the HIP error to stderr and aborts (the reference API
+ *     has no error channel); it never computes on the CPU instead;
  *   - simdpackFOR / simdunpackFOR accept unaligned pointers (the reference's
  *     need 16-byte alignment, src/simdfor.c:32,418).
  *

@@ -20,7 +20,8 @@
  *     The reference has no error channel (bit > 32 silently does nothing,
  *     src/simdbitpacking.c:14046); here bit > 32 is SIMDCOMP_HIP_EBIT.
  *   - a block's "initvalue" is the reference's initvalue argument: the
- *     differential seed for the d1 routines, the frame base for the FOR ones.
+ *     differential seed for the d1 routines, the frame base for the FOR ones;
+ *   - per-block widths (d_bits[k]) above 32 are read as 32 by every kernel.
  */
 #ifndef SIMDCOMP_HIP_H_
 #define SIMDCOMP_HIP_H_
@@ -47,6 +48,17 @@ extern "C" {
 int simdcomp_hip_version(void);
 /* Text of the most recent failure on the calling thread ("" if none). */
 const char *simdcomp_hip_last_error(void);
+
+/* The reference-signature host routines of simdcomp.h (simdpack, simdunpackd1,
+ * simdpack_length, ...) return void or a pointer, as in the reference
+ * (include/simdbitpacking.h:24-68): they cannot report that the GPU path failed
+ * (no device, out of memory, a HIP error).  By default such a failure prints to
+ * stderr and aborts.  A program may install a handler instead; it receives the
+ * message and `arg` and must not return (longjmp, exit, or throw through C++
+ * frames); if it does return the library aborts.  NULL restores the default.
+ * The batched entry points below never call it: they return error codes. */
+typedef void (*simdcomp_hip_error_handler)(const char *message, void *arg);
+void simdcomp_hip_set_error_handler(simdcomp_hip_error_handler handler, void *arg);
 
 /* ---- uniform width: block k's payload starts at d_out + k*16*bit ---------- */
 
@@ -225,7 +237,10 @@ int simdcomp_hip_stream_compress(int mode, uint32_t initvalue, const uint32_t *d
  * (SIMDCOMP_HIP_PLAIN) as one call: record index, chained offsets, in-place
  * unpack.  d_result as for simdcomp_hip_stream_index; when the stream holds
  * fewer than nblocks records the missing blocks decode as zero-width blocks
- * (check d_result[0] == nblocks and d_result[2] == 0).  d_workspace:
+ * (check d_result[0] == nblocks and d_result[2] == 0).  When d_result[2] is 1
+ * (bad width byte, or the stream ends inside a record) d_out is unspecified;
+ * nothing outside d_stream[0 .. stream_bytes) is read in any case: a record
+ * that does not fit is never indexed.  d_workspace:
  * simdcomp_hip_stream_decode_workspace(stream_bytes, nblocks) bytes. */
 size_t simdcomp_hip_stream_decode_workspace(size_t stream_bytes, size_t nblocks);
 int simdcomp_hip_stream_decode(int mode, uint32_t initvalue, const void *d_stream, size_t stream_bytes, size_t nblocks,

@@ -18,6 +18,7 @@ PLAIN, D1, FOR = 0, 1, 2
 DEVICE_API = {
     "simdcomp_hip_version": (C.c_int, []),
     "simdcomp_hip_last_error": (C.c_char_p, []),
+    "simdcomp_hip_set_error_handler": (None, [vp, vp]),
     "simdcomp_hip_pack": (C.c_int, [vp, vp, sz, u32, C.c_int, vp]),
     "simdcomp_hip_unpack": (C.c_int, [vp, vp, sz, u32, vp]),
     "simdcomp_hip_packd1": (C.c_int, [u32, vp, vp, vp, sz, u32, C.c_int, vp, vp]),

@@ -13,8 +13,10 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <atomic>
 #include <mutex>
 #include <string.h>
+#include <vector>
 
 #include "../../include/simdcomp.h"
 #include "../../include/simdcomp_hip.h"
@@ -24,8 +26,16 @@ namespace {
 
 constexpr size_t PIECE = (size_t)1 << 24;  // integers per pipeline piece (64 MiB), a multiple of 128
 
+std::atomic<simdcomp_hip_error_handler> g_handler{nullptr};
+std::atomic<void *> g_handler_arg{nullptr};
+
+// The reference's signatures have no error channel.  A failure of the GPU path goes to the handler the program
+// installed (which must not return: longjmp, exit, or a C++ throw through a C++ caller), else to stderr + abort.
 [[noreturn]] void die(const char *where, const char *what) {
-  fprintf(stderr, "simdcomp_hip: %s failed: %s\n", where, what);
+  char msg[320];
+  snprintf(msg, sizeof msg, "simdcomp_hip: %s failed: %s", where, what);
+  if (simdcomp_hip_error_handler h = g_handler.load()) h(msg, g_handler_arg.load());
+  fprintf(stderr, "%s\n", msg);
   abort();
 }
 
@@ -38,10 +48,15 @@ void ckapi(int rc, const char *where) {
 }
 
 constexpr size_t ZC_BYTES = 64 << 10;  // operands up to this size take the mapped-host-buffer path
+constexpr int MAX_DEVICES = 64;
 
+// Everything one host-API call needs on one device: two streams, two sets of staging buffers, the mapped host
+// buffers of the small-operand path.  A context is used by one thread at a time and never shared, so calls from
+// different threads run side by side like the reference's (which is stateless, src/simdbitpacking.c:14379-14399);
+// when a thread ends its contexts go back to a pool and serve the next new thread.  Contexts are never destroyed:
+// no HIP call is made from a destructor that may run while the process is exiting.
 struct Staging {
-  std::mutex mu;
-  bool ready = false;
+  int device = 0;
   hipStream_t stream[2] = {nullptr, nullptr};
   void *in[2] = {nullptr, nullptr};
   void *out[2] = {nullptr, nullptr};
@@ -51,20 +66,16 @@ struct Staging {
   // over PCIe and the call costs one launch and one synchronisation instead of two copies on top of those.
   uint8_t *zin = nullptr, *zout = nullptr;
 
-  void init() {
-    if (ready) return;
-    int n = 0;
-    ck(hipGetDeviceCount(&n), "hipGetDeviceCount");
-    if (n <= 0) die("device discovery", "no HIP device");
+  // with `device` current
+  void create(int dev) {
+    device = dev;
     for (int i = 0; i < 2; ++i) ck(hipStreamCreateWithFlags(&stream[i], hipStreamNonBlocking), "hipStreamCreate");
     ck(hipMalloc(reinterpret_cast<void **>(&result4), 64), "hipMalloc");
     ck(hipHostMalloc(reinterpret_cast<void **>(&zin), ZC_BYTES + 128, hipHostMallocMapped | hipHostMallocCoherent), "hipHostMalloc");
     ck(hipHostMalloc(reinterpret_cast<void **>(&zout), ZC_BYTES + 128, hipHostMallocMapped | hipHostMallocCoherent), "hipHostMalloc");
-    ready = true;
   }
 
   void reserve(int slot, size_t in_bytes, size_t out_bytes) {
-    init();
     in_bytes += 64;  // 16 bytes in front of din() hold the previous row of a piecewise FOR pack
     out_bytes += 64;
     if (in_bytes > in_cap[slot]) {
@@ -85,10 +96,92 @@ struct Staging {
   uint8_t *dout(int slot) { return static_cast<uint8_t *>(out[slot]); }
 };
 
-Staging &staging() {
-  static Staging s;
-  return s;
+struct Pool {
+  std::mutex mu;
+  std::vector<Staging *> idle[MAX_DEVICES];
+  std::vector<int> devices;  // SIMDCOMP_HIP_DEVICES, empty: the calling thread's current device
+  std::atomic<unsigned> next_thread{0};
+
+  Pool() {
+    int n = 0;
+    ck(hipGetDeviceCount(&n), "hipGetDeviceCount");
+    if (n <= 0) die("device discovery", "no HIP device");
+    // SIMDCOMP_HIP_DEVICES=0,2,5: host-API calls are spread over these GPUs, one per calling thread (threads take
+    // them in turn, in the order of their first call); unset: every call runs on the caller's current HIP device.
+    if (const char *e = getenv("SIMDCOMP_HIP_DEVICES")) {
+      const char *p = e;
+      while (*p) {
+        char *q = nullptr;
+        const long v = strtol(p, &q, 10);
+        if (q == p) die("SIMDCOMP_HIP_DEVICES", "expected a comma-separated list of device ordinals");
+        if (v < 0 || v >= n || v >= MAX_DEVICES) die("SIMDCOMP_HIP_DEVICES", "device ordinal out of range");
+        devices.push_back((int)v);
+        p = q;
+        while (*p == ',' || *p == ' ') ++p;
+      }
+    }
+  }
+};
+
+Pool &pool() {
+  static Pool *p = new Pool;  // never destroyed (see Staging)
+  return *p;
 }
+
+// The contexts the current thread holds, one per device it has used; handed back when the thread ends.
+struct Lease {
+  Staging *held[MAX_DEVICES] = {};
+  int assigned = -1;  // device taken from SIMDCOMP_HIP_DEVICES
+  ~Lease() {
+    bool any = false;
+    for (int d = 0; d < MAX_DEVICES; ++d) any = any || held[d];
+    if (!any) return;  // (a thread that never called the host API must not create the pool on its way out)
+    Pool &p = pool();
+    std::lock_guard<std::mutex> lock(p.mu);
+    for (int d = 0; d < MAX_DEVICES; ++d)
+      if (held[d]) p.idle[d].push_back(held[d]);
+  }
+};
+thread_local Lease t_lease;
+
+// Scope of one host-API call: picks the device, makes it current for the calling thread (and puts the caller's
+// device back afterwards), and provides that thread's context on it.
+struct Call {
+  int prev = -1, dev = -1;
+  Staging *ctx = nullptr;
+  Call() {
+    Pool &p = pool();
+    ck(hipGetDevice(&prev), "hipGetDevice");
+    if (p.devices.empty()) {
+      dev = prev;
+    } else {
+      if (t_lease.assigned < 0) t_lease.assigned = p.devices[p.next_thread.fetch_add(1) % p.devices.size()];
+      dev = t_lease.assigned;
+    }
+    if (dev < 0 || dev >= MAX_DEVICES) die("device selection", "device ordinal beyond the context table");
+    if (dev != prev) ck(hipSetDevice(dev), "hipSetDevice");
+    ctx = t_lease.held[dev];
+    if (!ctx) {
+      {
+        std::lock_guard<std::mutex> lock(p.mu);
+        if (!p.idle[dev].empty()) {
+          ctx = p.idle[dev].back();
+          p.idle[dev].pop_back();
+        }
+      }
+      if (!ctx) {
+        ctx = new Staging;
+        ctx->create(dev);
+      }
+      t_lease.held[dev] = ctx;
+    }
+  }
+  ~Call() {
+    if (dev != prev) (void)hipSetDevice(prev);
+  }
+  Call(const Call &) = delete;
+  Call &operator=(const Call &) = delete;
+};
 
 void h2d(void *dst, const void *src, size_t n, hipStream_t st) {
   if (n) ck(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, st), "hipMemcpyAsync H2D");
@@ -102,9 +195,8 @@ void d2h(void *dst, const void *src, size_t n, hipStream_t st) {
 // groups = 1: the 4-lane block of 128 integers; 2 / 4: one 8- / 16-lane block of 256 / 512 integers (plain mode)
 void block_pack(int mode, bool masked, uint32_t initvalue, const uint32_t *in, void *out, uint32_t bit, uint32_t groups = 1) {
   if (bit > 32) return;  // the reference's switch falls through and does nothing
-  Staging &s = staging();
-  std::lock_guard<std::mutex> lock(s.mu);
-  s.init();
+  Call call;
+  Staging &s = *call.ctx;
   hipStream_t st = s.stream[0];
   memcpy(s.zi(), in, 512 * (size_t)groups);
   sc::PackArgs a{};
@@ -122,9 +214,8 @@ void block_pack(int mode, bool masked, uint32_t initvalue, const uint32_t *in, v
 
 void block_unpack(int mode, uint32_t initvalue, const void *in, uint32_t *out, uint32_t bit, uint32_t groups = 1) {
   if (bit > 32) return;
-  Staging &s = staging();
-  std::lock_guard<std::mutex> lock(s.mu);
-  s.init();
+  Call call;
+  Staging &s = *call.ctx;
   hipStream_t st = s.stream[0];
   memcpy(s.zi(), in, 16 * (size_t)bit * groups);
   sc::UnpackArgs a{};
@@ -146,9 +237,8 @@ void reduce_host(const uint32_t *in, size_t length, uint32_t initvalue, uint32_t
   uint32_t acc[4] = {0, 0, 0xFFFFFFFFu, 0};  // what an empty range yields (src/simdcomputil.c:135-136)
   uint32_t prev = initvalue;
   if (length) {
-    Staging &s = staging();
-    std::lock_guard<std::mutex> lock(s.mu);
-    s.init();
+    Call call;
+    Staging &s = *call.ctx;
     hipStream_t st = s.stream[0];
     if (length * 4 <= ZC_BYTES) {
       // the input is read in place; the four results are accumulated with device atomics and stay in device memory
@@ -185,9 +275,8 @@ uint32_t width_of(uint32_t v) { return v ? 32u - (uint32_t)__builtin_clz(v) : 0u
 void *pack_length_host(int kind, uint32_t initvalue, const uint32_t *in, size_t length, void *out, uint32_t bit) {
   if (bit > 32 || bit == 0) return out;
   uint8_t *o = static_cast<uint8_t *>(out);
-  Staging &s = staging();
-  std::lock_guard<std::mutex> lock(s.mu);
-  s.init();
+  Call call;
+  Staging &s = *call.ctx;
   if (length * 4 <= ZC_BYTES) {
     const size_t nbytes = simdcomp_hip_compressedbytes(length, bit);
     hipStream_t st = s.stream[0];
@@ -225,9 +314,8 @@ const void *unpack_length_host(int kind, uint32_t initvalue, const void *in, siz
                                uint32_t bit) {
   if (bit > 32 || length == 0) return in;
   const uint8_t *p = static_cast<const uint8_t *>(in);
-  Staging &s = staging();
-  std::lock_guard<std::mutex> lock(s.mu);
-  s.init();
+  Call call;
+  Staging &s = *call.ctx;
   if (length * 4 <= ZC_BYTES) {
     const size_t nbytes = simdcomp_hip_compressedbytes(length, bit);
     hipStream_t st = s.stream[0];
@@ -261,6 +349,11 @@ const void *unpack_length_host(int kind, uint32_t initvalue, const void *in, siz
 }  // namespace
 
 extern "C" {
+
+void simdcomp_hip_set_error_handler(simdcomp_hip_error_handler handler, void *arg) {
+  g_handler_arg.store(arg);
+  g_handler.store(handler);
+}
 
 // ---- include/simdcomputil.h of the reference ------------------------------------
 uint32_t maxbits(const uint32_t *begin) { return maxbits_length(begin, SIMDBlockSize); }

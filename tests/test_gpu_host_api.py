@@ -193,3 +193,69 @@ def test_device_checksum_matches_host_formula():
     want = int(synth.splitmix64(idx ^ x.astype(np.uint64)).sum(dtype=np.uint64))
     acc = codec.checksum(torch.from_numpy(x.view(np.int32)).cuda(), index0=12345)
     assert int(acc[0].item()) & (2 ** 64 - 1) == want
+
+
+def test_concurrent_callers_on_disjoint_buffers(lib, orc):
+    """The reference is stateless (src/simdbitpacking.c:14379-14399 touch nothing but their arguments), so threads may
+    call it at the same time on disjoint buffers.  Four host threads do that here -- block calls, short and long
+    *_length calls, reductions -- and every result is compared with the oracle.  (ctypes drops the GIL during a
+    foreign call, so the calls really overlap.)"""
+    import threading
+
+    nthreads, errors = 4, []
+    start = threading.Barrier(nthreads)
+
+    def worker(t):
+        try:
+            rng_seed = 100 + t
+            n_long = (1 << 22) + 77 * (t + 1)  # several 64 KiB+ pieces through the staged path
+            bit = 5 + 6 * t
+            x_long = synth.random_bits(rng_seed, n_long, bit)
+            want_long = orc.simdpack_length(x_long, bit)
+            blocks = [synth.sorted_gaps(rng_seed + i, 128, min(bit, 20), first=t) for i in range(40)]
+            want_blocks = [orc.simdpackwithoutmaskd1(t, b, bit) for b in blocks]
+            start.wait()
+            for rep in range(3):
+                out = np.full(want_long.size + 64, 0xA5, np.uint8)
+                end = lib.simdpack_length(p(x_long), n_long, p(out), bit)
+                assert end - p(out) == want_long.size
+                assert np.array_equal(out[:want_long.size], want_long) and (out[want_long.size:] == 0xA5).all()
+                back = np.zeros(n_long, np.uint32)
+                lib.simdunpack_length(p(out), n_long, p(back), bit)
+                assert np.array_equal(back, x_long)
+                for b, w in zip(blocks, want_blocks):
+                    buf = np.zeros(16 * bit + 16, np.uint8)
+                    lib.simdpackwithoutmaskd1(t, p(b), p(buf), bit)
+                    assert np.array_equal(buf[:16 * bit], w)
+                    dec = np.zeros(128, np.uint32)
+                    lib.simdunpackd1(t, p(buf), p(dec), bit)
+                    assert np.array_equal(dec, b)
+                    assert lib.simdmaxbitsd1(t, p(b)) == orc.simdmaxbitsd1(t, b)
+                assert lib.maxbits_length(p(x_long), 100000) == orc.maxbits_length(x_long, 100000)
+        except BaseException as e:  # noqa: BLE001 -- reported by the main thread
+            errors.append((t, repr(e)))
+            try:
+                start.abort()
+            except Exception:
+                pass
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(nthreads)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=280)
+        assert not th.is_alive(), "a caller thread hung"
+    assert not errors, errors
+
+
+def test_host_api_follows_the_callers_current_device(lib, orc):
+    """A host call runs on the HIP device that is current in the calling thread (on a one-GPU box: device 0, before
+    and after), and leaves the caller's device selection as it found it."""
+    import torch
+
+    before = torch.cuda.current_device()
+    x = synth.random_bits(3, 128, 9)
+    buf = np.zeros(16 * 9, np.uint8)
+    lib.simdpack(p(x), p(buf), 9)
+    assert np.array_equal(buf, orc.simdpack(x, 9))
+    assert torch.cuda.current_device() == before

@@ -12,6 +12,7 @@ def declared_functions(path):
     text = open(path).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     text = re.sub(r"^\s*#.*$", "", text, flags=re.M)
+    text = re.sub(r"\btypedef\b[^;]*;", "", text)
     names = re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{]*\)\s*;", text)
     return sorted(set(n for n in names if n != "defined"))
 
