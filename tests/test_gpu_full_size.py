@@ -88,28 +88,61 @@ def sorted_ids(n, bit, seed):
     return torch.cumsum(gaps, 0, dtype=torch.int32)
 
 
-@pytest.mark.parametrize("bit", [1, 6, 13, 32])
-def test_posting_lists_2p30_d1(dev, orc, bit):
-    """Sorted posting lists, 2^30 docIDs: chained simdpackwithoutmaskd1 emitting the per-block offsets, simdunpackd1."""
+def test_posting_lists_2p30_d1(dev, orc):
+    """Sorted posting lists, 2^30 docIDs, at EVERY width 1..32: chained simdpackwithoutmaskd1 emitting the per-block
+    offsets, simdunpackd1 back (compared on the device), simdmaxbitsd1, and ~1000 sampled blocks per width compared
+    byte for byte with the oracle (payload, widths, and the decode of the oracle's own payload)."""
     import torch
 
     n = 1 << 30
     nblk = n // 128
-    ids = sorted_ids(n, bit, 10 + bit)
-    offsets = torch.empty(nblk, dtype=torch.int32, device="cuda")
-    payload = dev.packd1(ids, bit, initvalue=0, masked=False, initvalues_out=offsets)
-    # the chained offsets are the last value of the previous block
-    want_off = torch.cat([torch.zeros(1, dtype=torch.int32, device="cuda"), ids[127::128][:-1]])
-    assert torch.equal(offsets, want_off)
-    back = dev.unpackd1(offsets, payload, nblk, bit)
-    assert mismatches(dev, back, ids) == 0
-    widths = dev.maxbitsd1(ids, initvalue=0)
-    assert int(widths.max().item()) <= bit
+    gaps32 = randint32(n, 10)
     idx = sample_ids(nblk, 1024, 3)
-    xs, so = u32(ids.view(-1, 128)[idx]).reshape(-1), u32(offsets[idx])
-    got = payload.view(-1, 16 * bit)[idx].cpu().numpy().reshape(-1)
-    assert np.array_equal(got, orc.batch_pack("d1", xs, bit, seeds=so, masked=False))
-    assert np.array_equal(widths[idx].cpu().numpy(), orc.batch_maxbitsd1(so, xs))
+    offsets = torch.empty(nblk, dtype=torch.int32, device="cuda")
+    back = torch.empty(n, dtype=torch.int32, device="cuda")
+    for bit in range(1, 33):
+        ids = torch.cumsum(gaps32 if bit == 32 else gaps32 & ((1 << bit) - 1), 0, dtype=torch.int32)
+        payload = dev.packd1(ids, bit, initvalue=0, masked=False, initvalues_out=offsets)
+        # the chained offsets are the last value of the previous block
+        assert torch.equal(offsets[1:], ids[127::128][:-1]) and int(offsets[0].item()) == 0, bit
+        dev.unpackd1(offsets, payload, nblk, bit, out=back)
+        assert mismatches(dev, back, ids) == 0, bit
+        widths = dev.maxbitsd1(ids, initvalue=0)
+        assert int(widths.max().item()) <= bit, bit
+        xs, so = u32(ids.view(-1, 128)[idx]).reshape(-1), u32(offsets[idx])
+        got = payload.view(-1, 16 * bit)[idx].cpu().numpy().reshape(-1)
+        want = orc.batch_pack("d1", xs, bit, seeds=so, masked=False)
+        assert np.array_equal(got, want), bit
+        assert np.array_equal(widths[idx].cpu().numpy(), orc.batch_maxbitsd1(so, xs)), bit
+        assert np.array_equal(u32(back.view(-1, 128)[idx]).reshape(-1), orc.batch_unpack("d1", want, idx.numel(), bit, seeds=so)), bit
+        del ids, payload, widths
+
+
+def test_uniform_width_2p30_frame_of_reference(dev, orc):
+    """2^30 integers at one uniform width per run, simdpackFOR / simdunpackFOR with a per-block frame anywhere in 32
+    bits (value - frame wraps like uint32 where the cluster straddles 2^32): round trip on the device and sampled
+    blocks against the oracle."""
+    import torch
+
+    n = 1 << 30
+    nblk = n // 128
+    noise = randint32(n, 30)
+    bases = randint32(nblk, 31)
+    idx = sample_ids(nblk, 512, 6)
+    back = torch.empty(n, dtype=torch.int32, device="cuda")
+    for bit in (1, 5, 8, 11, 17, 24, 31, 32):
+        x = noise if bit == 32 else (noise & ((1 << bit) - 1)) + bases.repeat_interleave(128)
+        lo = bases
+        payload = dev.packFOR(lo, x, bit)
+        assert payload.numel() == nblk * 16 * bit
+        dev.unpackFOR(lo, payload, nblk, bit, out=back)
+        assert mismatches(dev, back, x) == 0, bit
+        xs, ss = u32(x.view(-1, 128)[idx]).reshape(-1), u32(lo[idx])
+        got = payload.view(-1, 16 * bit)[idx].cpu().numpy().reshape(-1)
+        want = orc.batch_pack("for", xs, bit, seeds=ss, masked=False)
+        assert np.array_equal(got, want), bit
+        assert np.array_equal(u32(back.view(-1, 128)[idx]).reshape(-1), orc.batch_unpack("for", want, idx.numel(), bit, seeds=ss)), bit
+        del x, payload
 
 
 def compare_mixed_sample(orc, mode, x, bits, off, payload, seeds, idx):

@@ -158,8 +158,8 @@ def test_index_rejects_bad_streams(dev, orc):
 @pytest.mark.parametrize("d1", [True, False])
 def test_decode_of_truncated_streams_reads_no_record_past_the_end(dev, orc, d1):
     """simdcomp_hip_stream_decode on streams that end inside their last record (one byte short; a last width byte of
-    32 with nothing behind it): reported in d_result[2], the cut record is not indexed (its width stays 0 in the
-    workspace, so no kernel reads a payload that lies beyond the stream), and the records in front decode as before."""
+    32 with nothing behind it): reported in d_result[2], the cut record is not decoded (no kernel reads a payload that
+    lies beyond the stream), and the records in front decode as before."""
     import torch
 
     from simdcomp_amd import binding as B
@@ -185,8 +185,6 @@ def test_decode_of_truncated_streams_reads_no_record_past_the_end(dev, orc, d1):
                                              torch.cuda.current_stream().cuda_stream), "stream_decode")
         torch.cuda.synchronize()
         assert res.tolist()[2] == 1
-        got_bits = ws[:nblk].cpu().numpy()
-        assert np.array_equal(got_bits[: nblk - 1], bits[: nblk - 1]) and got_bits[nblk - 1] == 0
         assert np.array_equal(u32(out)[: (nblk - 1) * 128], want[: (nblk - 1) * 128])
 
 
@@ -315,3 +313,114 @@ def test_index_adversarial_payloads(dev, orc, seed):
         if nblk <= 40000:
             out = dev.unpack_stream(PLAIN, to_dev(np.concatenate([stream, np.zeros(16, np.uint8)]))[:target], bits, off, nblk)
             assert np.array_equal(u32(out), orc.stream_decode(stream, nblk, d1=False))
+
+
+def decode_call(d1, d, nblk, init=0):
+    """simdcomp_hip_stream_decode through the C ABI on a device byte tensor; returns (integers, result[3])."""
+    import torch
+
+    from simdcomp_amd import binding as B
+
+    L = B.lib()
+    T = d.numel()
+    out = torch.full((nblk * 128 + 8,), 0x5A5A5A5A, dtype=torch.int32, device="cuda")
+    res = torch.zeros(3, dtype=torch.int64, device="cuda")
+    ws = torch.full((max(16, L.simdcomp_hip_stream_decode_workspace(T, nblk)),), 0xFF, dtype=torch.uint8, device="cuda")
+    B.check(L.simdcomp_hip_stream_decode(D1 if d1 else PLAIN, init & 0xFFFFFFFF, B.ptr(d), T, nblk,
+                                         B.ptr(out), B.ptr(res), B.ptr(ws), torch.cuda.current_stream().cuda_stream), "stream_decode")
+    torch.cuda.synchronize()
+    assert (out[nblk * 128:] == 0x5A5A5A5A).all(), "wrote past the last block"
+    return u32(out[: nblk * 128]), res.tolist()
+
+
+@pytest.mark.parametrize("seed", [4, 5])
+def test_decode_adversarial_payloads(dev, orc, seed):
+    """The one-call decode over streams whose payload bytes look like width bytes (false chains everywhere, several
+    chains surviving whole chunks, dense runs of zero-width records), lengths around the 2 KiB sub-chunk, 16 KiB chunk
+    and 4 MiB group boundaries: differential and plain, against the CPU loop of example.c over the oracle."""
+    rng = np.random.default_rng(seed)
+    for target in (1, 17, 2047, 2048, 2049, 16384 - 1, 16384, 16384 + 1, 5 * 16384 + 100, 256 * 16384 - 7, 256 * 16384 + 513):
+        widths = []
+        total = 0
+        while True:
+            w = int(rng.choice([0, 0, 0, 1, 2, 3, 5, 8, 13, 20, 31, 32]))
+            if total + 1 + 16 * w > target:
+                break
+            widths.append(w)
+            total += 1 + 16 * w
+        while total < target:
+            widths.append(0)
+            total += 1
+        widths = np.array(widths, np.uint8)
+        nblk = widths.size
+        pos = np.concatenate([[0], np.cumsum(1 + 16 * widths.astype(np.int64))])[:-1]
+        stream = rng.integers(0, 256, target, dtype=np.uint8)
+        low = rng.random(target) < 0.5
+        stream[low] = rng.integers(0, 33, int(low.sum()), dtype=np.uint8)
+        stream[rng.random(target) < 0.2] = 0
+        stream[pos] = widths
+        d = to_dev(stream)
+        for d1 in (True, False):
+            for init in (0, 0xFFFFFF00):
+                got, res = decode_call(d1, d, nblk, init)
+                assert res == [nblk, target - nblk, 0], (target, d1)
+                want = orc.stream_decode(stream, nblk, d1=d1, initvalue=init)
+                assert np.array_equal(got, want), (target, d1, init)
+
+
+def test_decode_dense_and_wide_records(dev, orc):
+    """All-zero widths (a record per byte, 16384 records per chunk, every block a copy of the start value), all-32
+    widths (raw blocks, the chain restarts at each), and long runs of each in one stream."""
+    n0 = 70001
+    z = to_dev(np.zeros(n0, np.uint8))
+    got, res = decode_call(True, z, n0, 0xABCD1234)
+    assert res == [n0, 0, 0] and (got == 0xABCD1234).all()
+    got, res = decode_call(False, z, n0)
+    assert res == [n0, 0, 0] and (got == 0).all()
+    nblk = 1500
+    x = (np.arange(nblk * 128, dtype=np.uint32) * np.uint32(2654435761)) ^ np.uint32(0x5A5A5A5A)
+    s32 = orc.stream_compress(x, d1=True)
+    assert s32.size == nblk * 513
+    got, res = decode_call(True, to_dev(s32), nblk)
+    assert res == [nblk, nblk * 512, 0] and np.array_equal(got, x)
+    # runs: 40000 zero-width records, 300 raw blocks, 40000 zero-width records, a few narrow blocks
+    y = G.stream_corpus(5, 64)
+    tail = orc.stream_compress(y, d1=True, initvalue=int(x[300 * 128 - 1]))
+    mixed = np.concatenate([np.zeros(40000, np.uint8), s32[: 300 * 513], np.zeros(40000, np.uint8), tail])
+    n = 80000 + 300 + 64
+    for d1 in (True, False):
+        got, res = decode_call(d1, to_dev(mixed), n, 77)
+        assert res[0] == n and res[2] == 0
+        assert np.array_equal(got, orc.stream_decode(mixed, n, d1=d1, initvalue=77))
+
+
+@pytest.mark.parametrize("d1", [True, False])
+def test_decode_large_stream_every_alignment(dev, d1):
+    """2^26 integers (several thousand chunks: the chain crosses many look-back windows), the stream at odd addresses,
+    fewer and more blocks asked for than the stream holds."""
+    import torch
+
+    nblk = (1 << 26) // 128
+    g = torch.Generator(device="cuda")
+    g.manual_seed(11)
+    w = torch.minimum(torch.randint(0, 25, (nblk,), device="cuda", generator=g), torch.randint(0, 25, (nblk,), device="cuda", generator=g))
+    gaps = torch.randint(0, 1 << 30, (nblk * 128,), dtype=torch.int32, device="cuda", generator=g)
+    gaps &= ((1 << w) - 1).to(torch.int32).repeat_interleave(128)
+    ids = torch.cumsum(gaps, 0, dtype=torch.int32)
+    wild = torch.randint(0, nblk, (nblk // 40,), device="cuda", generator=g)
+    ids.view(-1, 128)[wild] = torch.randint(-2 ** 31, 2 ** 31 - 1, (wild.numel(), 128), dtype=torch.int32, device="cuda", generator=g)
+    mode = D1 if d1 else PLAIN
+    buf, nbytes = dev.stream_compress(mode, ids)
+    T = int(nbytes.item())
+    for shift in (0, 1, 7):
+        shifted = torch.empty(T + 16, dtype=torch.uint8, device="cuda")
+        shifted[shift:shift + T] = buf[:T]
+        out, res = dev.stream_decode(mode, shifted[shift:shift + T], nblk)
+        assert res.tolist() == [nblk, T - nblk, 0]
+        assert torch.equal(out, ids)
+    out, res = dev.stream_decode(mode, buf[:T], nblk - 1000)
+    assert res.tolist()[0] == nblk and torch.equal(out, ids[: (nblk - 1000) * 128])
+    out, res = dev.stream_decode(mode, buf[:T], nblk + 50)
+    assert res.tolist()[0] == nblk and torch.equal(out[: nblk * 128], ids)
+    surplus = out[nblk * 128:]
+    assert (surplus == (ids[-1] if d1 else 0)).all()

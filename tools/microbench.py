@@ -114,6 +114,17 @@ def stream(n, nblk, reps):
         "maxbitsd1": (lambda: codec.maxbitsd1(ids, initvalue=0, initvalues_out=seeds), 517 * nblk),
         "payload_offsets": (lambda: codec.payload_offsets(bits), 9 * nblk),
     }
+    # the decode loop as one call (record index + chained decode straight from the bytes)
+    ws_d = torch.empty(max(16, L.simdcomp_hip_stream_decode_workspace(T + nblk, nblk)), dtype=torch.uint8, device=dev)
+    for mode, name in ((1, "stream_decode"), (0, "stream_decode_plain")):
+        binding.check(L.simdcomp_hip_stream_decode(mode, 0, P(strm), T + nblk, nblk, P(out), P(r3), P(ws_d), st), name)
+        assert r3.tolist() == [nblk, T, 0], r3.tolist()
+        if mode == 1:
+            assert torch.equal(out, ids), "stream_decode differs from the input"
+        else:
+            assert torch.equal(out, codec.unpack_stream(0, strm, bits, off, nblk)), "plain stream_decode differs"
+        rows[name] = ((lambda m: lambda: L.simdcomp_hip_stream_decode(m, 0, P(strm), T + nblk, nblk, P(out), P(r3), P(ws_d), st))(mode),
+                      512 * nblk + T + nblk)
     res = {"avg_bits": round(T / nblk / 16, 2), "stream_MiB": round((T + nblk) / 2 ** 20, 1)}
     for name, (f, by) in rows.items():
         t = timeit(f, reps)
