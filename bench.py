@@ -328,6 +328,22 @@ def cpu_baseline(corpora, dev, log2n=26, reps=3):
             "blocks_compared_per_width": nb, "per_width_Gint/s": per_width, "avx2_comparator": avx2}
 
 
+def box_facts():
+    """What sysfs says about the GPUs of this box (serial number, firmware, partition modes, clock tables): per-width
+    rates come out in two populations across boxes, and this is what tells the boxes apart afterwards."""
+    import glob
+
+    facts = {}
+    for d in sorted(glob.glob("/sys/class/drm/card*/device")):
+        for name in ("unique_id", "vbios_version", "current_compute_partition", "current_memory_partition", "pp_dpm_mclk",
+                     "pp_dpm_sclk", "power_dpm_force_performance_level"):
+            try:
+                facts[os.path.basename(os.path.dirname(d)) + "/" + name] = open(os.path.join(d, name)).read().strip().replace("\n", " | ")
+            except OSError:
+                pass
+    return facts
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -712,6 +728,7 @@ def main():
                          "per_width": table},
         }
         line["roofline"]["measured_ceilings"] = ceilings(out)
+        line["box"] = box_facts()
     del out
     if not a.no_encode:
         barrier()
