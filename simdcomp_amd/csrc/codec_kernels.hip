@@ -1074,8 +1074,12 @@ constexpr size_t PREFETCH_DISTANCE_BYTES = (size_t)20 << 20;
 #define SC_PM_BS 256
 #define SC_PM_U 2
 #endif
-constexpr int pack_threads(int b) { return b < 0 ? SC_PM_BS : ((b > 0 && b <= 7) ? 128 : 256); }
-constexpr int pack_steps(int b) { return b < 0 ? SC_PM_U : (b <= 7 ? 2 : 1); }
+#ifndef SC_PN_BS
+#define SC_PN_BS 128
+#define SC_PN_U 2
+#endif
+constexpr int pack_threads(int b) { return b < 0 ? SC_PM_BS : ((b > 0 && b <= 7) ? (b >= 4 ? SC_PN_BS : 128) : 256); }
+constexpr int pack_steps(int b) { return b < 0 ? SC_PM_U : (b <= 7 ? (b >= 4 ? SC_PN_U : 2) : 1); }
 
 // index 0 is the per-block-width instance (B = -1), index 1 + b the uniform width b
 template <int MODE, int BP1, int LS = 0>
