@@ -442,7 +442,7 @@ __device__ __forceinline__ void touch_bytes(const void *base, size_t byte0, size
 // LS > 0: the wide layouts (2^LS four-lane groups per block, see UnpackArgs::lane_groups): group g of wide block W is
 // "block" W * 2^LS + g here, its payload vectors and output rows 2^LS apart.  Uniform widths, plain coding only.
 template <int B, int MODE, int U, int BS, int PF = 0, int LS = 0>
-__global__ __launch_bounds__(BS) void k_unpack_fast(UnpackArgs a, uint32_t nwg = 0, uint32_t dist = 0) {
+__global__ __launch_bounds__(BS) void k_unpack_fast(UnpackArgs a, uint32_t nwg = 0, uint32_t dist = 0, uint32_t dist2 = 0) {
   static_assert(LS == 0 || (B >= 0 && MODE == MODE_PLAIN), "wide layouts: uniform width, plain coding");
   __shared__ u32x4 lds[BS / 64][2][33];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -456,18 +456,24 @@ __global__ __launch_bounds__(BS) void k_unpack_fast(UnpackArgs a, uint32_t nwg =
     static_assert(B > 0, "prefetch groups are for uniform widths");
     const uint32_t group = blockIdx.x / (PF + 1), r = blockIdx.x - group * (PF + 1);
     if (r == 0) {
-      // groups [t0, t1): two per prefetcher while the distance ramps up from the start of the array, one after
-      const size_t t0 = (size_t)group + (group + 1 < dist ? group + 1 : dist);
-      const size_t t1 = (size_t)group + 1 + (group + 2 < dist ? group + 2 : dist);
+      // groups [t0, t1): two per prefetcher while the distance ramps up from the start of the array, one after.
+      // dist2 (0: none) is a second, nearer distance: the same bytes are touched again closer to their use, a cache
+      // hit where the first touch is still resident and the real prefetch where it is not (see prefetch_distance2)
       constexpr size_t GB = (size_t)PF * per_iter;
       const size_t nblk = (size_t)nwg * per_iter;
       u32x4 acc = {0, 0, 0, 0};
-      for (size_t t = t0; t < t1; ++t) {
-        if (t * GB >= nblk) break;
-        touch_bytes<BS, GB * B * 16>(a.payload, t * GB * B * 16, nblk * B * 16 - 1, acc);
-        // (no seed array: the same bytes of the payload are touched instead, which keeps this path free of branches)
-        if constexpr (MODE != MODE_PLAIN)
-          touch_bytes<BS, GB * 4>(a.seeds ? static_cast<const void *>(a.seeds) : a.payload, t * GB * 4, nblk * 4 - 1, acc);
+      for (int pass = 0; pass < 2; ++pass) {
+        const uint32_t d = pass ? dist2 : dist;
+        if (d == 0) break;
+        const size_t t0 = (size_t)group + (group + 1 < d ? group + 1 : d);
+        const size_t t1 = (size_t)group + 1 + (group + 2 < d ? group + 2 : d);
+        for (size_t t = t0; t < t1; ++t) {
+          if (t * GB >= nblk) break;
+          touch_bytes<BS, GB * B * 16>(a.payload, t * GB * B * 16, nblk * B * 16 - 1, acc);
+          // (no seed array: the same bytes of the payload are touched instead, which keeps this path free of branches)
+          if constexpr (MODE != MODE_PLAIN)
+            touch_bytes<BS, GB * 4>(a.seeds ? static_cast<const void *>(a.seeds) : a.payload, t * GB * 4, nblk * 4 - 1, acc);
+        }
       }
       asm volatile("" ::"v"(acc));  // keeps the loads; the only wait of this workgroup
       return;
@@ -1053,11 +1059,18 @@ constexpr int REDUCE_U = SC_REDUCE_U;
 // to cover the payload read in front of the stores) or 2 KiB per workgroup;
 // very wide blocks prefer 256 threads.  The per-block-width kernels chase two
 // dependent loads (offset, then payload) and measured best with four steps.
-constexpr int unpack_threads(int b) { return (b < 0 || b >= 28) ? 256 : 128; }
+#ifndef SC_UN_BS
+#define SC_UN_BS 128
+#define SC_UN_U 2
+#endif
+#ifndef SC_UN_MAXB
+#define SC_UN_MAXB 0
+#endif
+constexpr int unpack_threads(int b) { return (b < 0 || b >= 28) ? 256 : ((b >= 1 && b <= SC_UN_MAXB) ? SC_UN_BS : 128); }
 #ifndef SC_MIXED_UNPACK_STEPS
 #define SC_MIXED_UNPACK_STEPS 4
 #endif
-constexpr int unpack_steps(int b) { return b < 0 ? SC_MIXED_UNPACK_STEPS : (b <= 14 ? 2 : 1); }
+constexpr int unpack_steps(int b) { return b < 0 ? SC_MIXED_UNPACK_STEPS : ((b >= 1 && b <= SC_UN_MAXB) ? SC_UN_U : (b <= 14 ? 2 : 1)); }
 // Widths 1..7 gain 3-17 points of HBM peak from dedicated prefetch workgroups
 // (one per 16 decode workgroups, 20 MiB of output ahead: the plateau of a
 // sweep over group size 8..512 and distance 4..64 MiB); from 8 bits on the
@@ -1065,8 +1078,27 @@ constexpr int unpack_steps(int b) { return b < 0 ? SC_MIXED_UNPACK_STEPS : (b <=
 // more than the latency they hide.  The per-block-width decoder does not gain
 // either: its prefetcher has to chase offsets itself and its scattered touches
 // cost more than they save.
-constexpr int unpack_prefetch_group(int b) { return (b >= 1 && b <= 7) ? 16 : 0; }
-constexpr size_t PREFETCH_DISTANCE_BYTES = (size_t)20 << 20;
+#ifndef SC_PF_GROUP
+#define SC_PF_GROUP 16
+#endif
+#ifndef SC_PF_DIST_MIB
+#define SC_PF_DIST_MIB 20
+#endif
+#ifndef SC_PF_MAXB
+#define SC_PF_MAXB 7
+#endif
+constexpr int unpack_prefetch_group(int b) { return (b >= 1 && b <= SC_PF_MAXB) ? SC_PF_GROUP : 0; }
+#ifndef SC_PF_DIST1_MIB
+#define SC_PF_DIST1_MIB 10
+#endif
+constexpr size_t prefetch_distance_bytes(int b) { return (size_t)(b == 1 ? SC_PF_DIST1_MIB : SC_PF_DIST_MIB) << 20; }
+#ifndef SC_PF_DIST2_MIB
+#define SC_PF_DIST2_MIB 0
+#endif
+#ifndef SC_PF_DIST2_MAXB
+#define SC_PF_DIST2_MAXB 1
+#endif
+constexpr size_t prefetch_distance2_bytes(int b) { return (size_t)(b <= SC_PF_DIST2_MAXB ? SC_PF_DIST2_MIB : 0) << 20; }
 // The encoders read 512 bytes per block whatever the width.  Shapes from sweeps at 2^30 integers after the segmented
 // scan was brought down to two instructions per component and step (before that b = 3, five steps, was bound by
 // vector-ALU work and wanted 256 x 4): 128 x 2 for b <= 7, 256 x 1 above, 256 x 2 for per-block widths.
@@ -1091,9 +1123,10 @@ static size_t launch_unpack_fast(const UnpackArgs &a, hipStream_t st) {
   if (nwg == 0) return 0;
   if constexpr (PF > 0) {
     const size_t groups = (nwg + PF - 1) / PF;
-    const size_t dist = PREFETCH_DISTANCE_BYTES / (PF * per_wg * 512);
+    const size_t dist = prefetch_distance_bytes(BP1 - 1) / (PF * per_wg * 512);
+    const size_t dist2 = prefetch_distance2_bytes(BP1 - 1) / (PF * per_wg * 512);
     hipLaunchKernelGGL((k_unpack_fast<BP1 - 1, MODE, U, BS, PF, LS>), dim3((unsigned)(groups * (PF + 1))), dim3(BS), 0, st, a,
-                       (uint32_t)nwg, (uint32_t)dist);
+                       (uint32_t)nwg, (uint32_t)dist, (uint32_t)dist2);
   } else {
     hipLaunchKernelGGL((k_unpack_fast<BP1 - 1, MODE, U, BS, 0, LS>), dim3((unsigned)nwg), dim3(BS), 0, st, a, 0u, 0u);
   }
