@@ -441,6 +441,14 @@ __device__ __forceinline__ void touch_bytes(const void *base, size_t byte0, size
 
 // LS > 0: the wide layouts (2^LS four-lane groups per block, see UnpackArgs::lane_groups): group g of wide block W is
 // "block" W * 2^LS + g here, its payload vectors and output rows 2^LS apart.  Uniform widths, plain coding only.
+// From 24 bits on the payload is read with non-temporal loads: it is nearly half of the traffic there and read
+// once, and keeping it out of the caches' way measured +2..+4 points of HBM peak for b = 26..32 (neutral below).
+#ifndef SC_NT_PAYLOAD_MINB
+#define SC_NT_PAYLOAD_MINB 24
+#endif
+#ifndef SC_NT_MIXED_UNPACK
+#define SC_NT_MIXED_UNPACK 0
+#endif
 template <int B, int MODE, int U, int BS, int PF = 0, int LS = 0>
 __global__ __launch_bounds__(BS) void k_unpack_fast(UnpackArgs a, uint32_t nwg = 0, uint32_t dist = 0, uint32_t dist2 = 0) {
   static_assert(LS == 0 || (B >= 0 && MODE == MODE_PLAIN), "wide layouts: uniform width, plain coding");
@@ -528,7 +536,10 @@ __global__ __launch_bounds__(BS) void k_unpack_fast(UnpackArgs a, uint32_t nwg =
     }
     if constexpr (B != 0) {
 #pragma unroll
-      for (int u = 0; u < U; ++u) ld[u] = load_global_at(reinterpret_cast<uintptr_t>(src[u]));
+      for (int u = 0; u < U; ++u) {
+        if constexpr (B >= SC_NT_PAYLOAD_MINB || (B < 0 && SC_NT_MIXED_UNPACK)) ld[u] = __builtin_nontemporal_load(reinterpret_cast<const __attribute__((address_space(1))) u32x4_u *>(reinterpret_cast<uintptr_t>(src[u])));
+        else ld[u] = load_global_at(reinterpret_cast<uintptr_t>(src[u]));
+      }
     }
     if constexpr (B >= 0 && MODE != MODE_PLAIN) {
       // The seeds of the wave's 2 * U consecutive blocks: one coalesced load, handed out through scalar registers.
@@ -577,6 +588,15 @@ __global__ __launch_bounds__(BS) void k_unpack_fast(UnpackArgs a, uint32_t nwg =
 // GENERIC: full blocks of the reference's arbitrary-length frame-of-reference packer (src/simdfor.c:15043
 // simdpackFOR_length): a field that ends exactly on a word boundary still hands value >> b to the next word, across
 // block boundaries too (visible only for out-of-range input).  The partial last block stays with k_pack_flex.
+#ifndef SC_NT_PACK_MINB
+#define SC_NT_PACK_MINB 1
+#endif
+#ifndef SC_NT_PACKIN_MINB
+#define SC_NT_PACKIN_MINB 1
+#endif
+#ifndef SC_NT_MIXED
+#define SC_NT_MIXED 1
+#endif
 template <int B, int MODE, bool MASKED, int U, int BS, int LS = 0, bool GENERIC = false>
 __global__ __launch_bounds__(BS) void k_pack_fast(PackArgs a) {
   static_assert(LS == 0 || (B >= 0 && MODE == MODE_PLAIN), "wide layouts: uniform width, plain coding");
@@ -595,7 +615,11 @@ __global__ __launch_bounds__(BS) void k_pack_fast(PackArgs a) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const size_t blk = first + 2 * (size_t)u;
-      x[u] = stream_load(reinterpret_cast<const u32x4 *>(a.in + (((blk >> LS) * 128) << LS) + 4 * (blk & ((1u << LS) - 1)) + ((4 * (size_t)k) << LS)));
+      {
+        const u32x4 *row = reinterpret_cast<const u32x4 *>(a.in + (((blk >> LS) * 128) << LS) + 4 * (blk & ((1u << LS) - 1)) + ((4 * (size_t)k) << LS));
+        if constexpr (B >= SC_NT_PACKIN_MINB || (B < 0 && SC_NT_MIXED)) x[u] = __builtin_nontemporal_load(row);
+        else x[u] = stream_load(row);
+      }
       if constexpr (B >= 0) {
         b[u] = B;
         pbase[u] = reinterpret_cast<uint8_t *>(payload + (((blk >> LS) * (size_t)B) << LS) + (blk & ((1u << LS) - 1)));
@@ -724,15 +748,23 @@ __global__ __launch_bounds__(BS) void k_pack_fast(PackArgs a) {
       const uint32_t bu = b[u];
       const uint32_t w = ((uint32_t)k * bu) >> 5;
       if constexpr (B == 32) {
-        *reinterpret_cast<u32x4 *>(pbase[u] + ((16 * k) << LS)) = x[u];
+        if constexpr (B >= SC_NT_PACK_MINB) __builtin_nontemporal_store(x[u], reinterpret_cast<u32x4 *>(pbase[u] + ((16 * k) << LS)));
+        else *reinterpret_cast<u32x4 *>(pbase[u] + ((16 * k) << LS)) = x[u];
       } else if constexpr (B > 0) {
         const bool last = (k == 31) || ((((uint32_t)(k + 1) * bu) >> 5) != w);
-        if (last) *reinterpret_cast<u32x4 *>(pbase[u] + ((16 * w) << LS)) = acc[u];
+        if constexpr (B >= SC_NT_PACK_MINB) {
+          if (last) __builtin_nontemporal_store(acc[u], reinterpret_cast<u32x4 *>(pbase[u] + ((16 * w) << LS)));
+        } else {
+          if (last) *reinterpret_cast<u32x4 *>(pbase[u] + ((16 * w) << LS)) = acc[u];
+        }
       } else if constexpr (B < 0) {
         const bool raw = bu == 32;
         const bool last = (k == 31) || ((((uint32_t)(k + 1) * bu) >> 5) != w);
         const u32x4 val = raw ? x[u] : acc[u];
-        if (bu != 0 && (raw || last)) *reinterpret_cast<u32x4_u *>(pbase[u] + 16 * w) = val;  // raw: w == k
+        if (bu != 0 && (raw || last)) {  // raw: w == k
+          if constexpr (SC_NT_MIXED) __builtin_nontemporal_store(val, reinterpret_cast<u32x4_u *>(pbase[u] + 16 * w));
+          else *reinterpret_cast<u32x4_u *>(pbase[u] + 16 * w) = val;
+        }
         if (a.stream_layout && k == 0) pbase[u][-1] = (uint8_t)bu;
       }
     }
@@ -748,6 +780,17 @@ __global__ __launch_bounds__(BS) void k_pack_fast(PackArgs a) {
 // ---------------------------------------------------------------------------
 // per-block reductions: maxbits / maxbitsd1 / min-max (+ frame width)
 // ---------------------------------------------------------------------------
+#ifndef SC_NT_REDUCE
+#define SC_NT_REDUCE 1
+#endif
+__device__ __forceinline__ u32x4 reduce_load(const u32x4 *p) {
+#if SC_NT_REDUCE
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+
 template <int WHAT, int U>
 __global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -779,7 +822,7 @@ __global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
       }
     } else {
 #pragma unroll
-      for (int u = 0; u < U; ++u) x[u] = stream_load(reinterpret_cast<const u32x4 *>(a.in + bc[u] * 128 + 4 * k));
+      for (int u = 0; u < U; ++u) x[u] = reduce_load(reinterpret_cast<const u32x4 *>(a.in + bc[u] * 128 + 4 * k));
     }
     if constexpr (WHAT == RED_MAXBITSD1) {
       // explicit offsets, or chained from the input: block k starts from in[128k-1], block 0 from seed0.  Chained,
@@ -1066,11 +1109,16 @@ constexpr int REDUCE_U = SC_REDUCE_U;
 #ifndef SC_UN_MAXB
 #define SC_UN_MAXB 0
 #endif
-constexpr int unpack_threads(int b) { return (b < 0 || b >= 28) ? 256 : ((b >= 1 && b <= SC_UN_MAXB) ? SC_UN_BS : 128); }
+#ifndef SC_UW_MINB
+#define SC_UW_MINB 99
+#define SC_UW_BS 256
+#define SC_UW_U 1
+#endif
+constexpr int unpack_threads(int b) { return b >= SC_UW_MINB ? SC_UW_BS : ((b < 0 || b >= 28) ? 256 : ((b >= 1 && b <= SC_UN_MAXB) ? SC_UN_BS : 128)); }
 #ifndef SC_MIXED_UNPACK_STEPS
 #define SC_MIXED_UNPACK_STEPS 4
 #endif
-constexpr int unpack_steps(int b) { return b < 0 ? SC_MIXED_UNPACK_STEPS : ((b >= 1 && b <= SC_UN_MAXB) ? SC_UN_U : (b <= 14 ? 2 : 1)); }
+constexpr int unpack_steps(int b) { return b >= SC_UW_MINB ? SC_UW_U : (b < 0 ? SC_MIXED_UNPACK_STEPS : ((b >= 1 && b <= SC_UN_MAXB) ? SC_UN_U : (b <= 14 ? 2 : 1))); }
 // Widths 1..7 gain 3-17 points of HBM peak from dedicated prefetch workgroups
 // (one per 16 decode workgroups, 20 MiB of output ahead: the plateau of a
 // sweep over group size 8..512 and distance 4..64 MiB); from 8 bits on the

@@ -45,6 +45,10 @@ __device__ __forceinline__ T load_global_as(uintptr_t at) {
 __device__ __forceinline__ u32x4 load_global_at(uintptr_t at) {
   return *(const __attribute__((address_space(1))) u32x4_u *)at;
 }
+// The same, non-temporal: for bytes that are read once and should not displace what the caches hold.
+__device__ __forceinline__ u32x4 load_global_nt(uintptr_t at) {
+  return __builtin_nontemporal_load((const __attribute__((address_space(1))) u32x4_u *)at);
+}
 
 constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118;
 constexpr int DPP_ROW_BCAST15 = 0x142;

@@ -16,6 +16,13 @@
 
 #include "lane_ops.h"
 
+#ifndef SC_NT_SUMS
+#define SC_NT_SUMS 0
+#endif
+#ifndef SC_NT_COPY
+#define SC_NT_COPY 0
+#endif
+
 namespace sc {
 
 // ---------------------------------------------------------------------------
@@ -59,7 +66,7 @@ __global__ __launch_bounds__(256) void k_block_sums(const uint8_t *payload, cons
     const uint32_t last = b[u] ? b[u] - 1 : 0;
     uintptr_t at = reinterpret_cast<uintptr_t>(payload) + o[u] + 16 * ((uint32_t)k < last ? (uint32_t)k : last);
     at = (uint32_t)k > last ? (at & ~(uintptr_t)15) : at;  // idle lanes: an aligned address coalesces better
-    ld[u] = load_global_at(b[u] ? at : reinterpret_cast<uintptr_t>(sums));
+    ld[u] = SC_NT_SUMS ? load_global_nt(b[u] ? at : reinterpret_cast<uintptr_t>(sums)) : load_global_at(b[u] ? at : reinterpret_cast<uintptr_t>(sums));
   }
   uint32_t mine_out = 0;
 #pragma unroll
@@ -244,7 +251,7 @@ __global__ __launch_bounds__(256) void k_stream_copy(const uint8_t *src, uint8_t
     // there): behind a branch each of the U loads would wait for the one before
     uintptr_t at = reinterpret_cast<uintptr_t>(src + from);
     at = (uint32_t)k > last ? (at & ~(uintptr_t)15) : at;  // idle lanes: an aligned address coalesces better
-    x[u] = load_global_at(b[u] ? at : reinterpret_cast<uintptr_t>(&g_nothing));
+    x[u] = SC_NT_COPY ? load_global_nt(b[u] ? at : reinterpret_cast<uintptr_t>(&g_nothing)) : load_global_at(b[u] ? at : reinterpret_cast<uintptr_t>(&g_nothing));
   }
 #pragma unroll
   for (int u = 0; u < U; ++u) {
@@ -252,7 +259,10 @@ __global__ __launch_bounds__(256) void k_stream_copy(const uint8_t *src, uint8_t
     if (blk >= nblocks) continue;
     uint8_t *to = dst + o[u] + (TO_STREAM ? blk + 1 : 0);
     if (TO_STREAM && k == 0) to[-1] = (uint8_t)b[u];
-    if ((uint32_t)k < b[u]) *reinterpret_cast<u32x4_u *>(to + 16 * k) = x[u];
+    if ((uint32_t)k < b[u]) {
+      if (SC_NT_COPY) __builtin_nontemporal_store(x[u], reinterpret_cast<u32x4_u *>(to + 16 * k));
+      else *reinterpret_cast<u32x4_u *>(to + 16 * k) = x[u];
+    }
   }
 }
 
