@@ -1147,9 +1147,9 @@ constexpr size_t prefetch_distance_bytes(int b) { return (size_t)(b == 1 ? SC_PF
 #define SC_PF_DIST2_MAXB 1
 #endif
 constexpr size_t prefetch_distance2_bytes(int b) { return (size_t)(b <= SC_PF_DIST2_MAXB ? SC_PF_DIST2_MIB : 0) << 20; }
-// The encoders read 512 bytes per block whatever the width.  Shapes from sweeps at 2^30 integers after the segmented
-// scan was brought down to two instructions per component and step (before that b = 3, five steps, was bound by
-// vector-ALU work and wanted 256 x 4): 128 x 2 for b <= 7, 256 x 1 above, 256 x 2 for per-block widths.
+// The encoders read 512 bytes per block whatever the width.  Shapes from sweeps at 2^30 integers with non-temporal
+// input loads and payload stores (64 / 128 / 256 threads x 1 / 2 / 4 steps): 128 x 2 for b <= 12 and b = 16 (b = 8:
+// 74 -> 83 % against 256 x 1), 256 x 1 for the other widths, 256 x 2 for per-block widths.
 #ifndef SC_PM_BS
 #define SC_PM_BS 256
 #define SC_PM_U 2
@@ -1158,8 +1158,15 @@ constexpr size_t prefetch_distance2_bytes(int b) { return (size_t)(b <= SC_PF_DI
 #define SC_PN_BS 128
 #define SC_PN_U 2
 #endif
-constexpr int pack_threads(int b) { return b < 0 ? SC_PM_BS : ((b > 0 && b <= 7) ? (b >= 4 ? SC_PN_BS : 128) : 256); }
-constexpr int pack_steps(int b) { return b < 0 ? SC_PM_U : (b <= 7 ? (b >= 4 ? SC_PN_U : 2) : 1); }
+#ifndef SC_PW_LO
+#define SC_PW_LO 99
+#define SC_PW_HI 0
+#define SC_PW_BS 256
+#define SC_PW_U 1
+#endif
+constexpr bool pack_narrow_shape(int b) { return (b > 0 && b <= 12) || b == 16; }
+constexpr int pack_threads(int b) { return (b >= SC_PW_LO && b <= SC_PW_HI) ? SC_PW_BS : (b < 0 ? SC_PM_BS : (pack_narrow_shape(b) ? (b >= 4 ? SC_PN_BS : 128) : 256)); }
+constexpr int pack_steps(int b) { return (b >= SC_PW_LO && b <= SC_PW_HI) ? SC_PW_U : (b < 0 ? SC_PM_U : (pack_narrow_shape(b) ? (b >= 4 ? SC_PN_U : 2) : 1)); }
 
 // index 0 is the per-block-width instance (B = -1), index 1 + b the uniform width b
 template <int MODE, int BP1, int LS = 0>
