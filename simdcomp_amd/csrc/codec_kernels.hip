@@ -450,7 +450,7 @@ __device__ __forceinline__ void touch_bytes(const void *base, size_t byte0, size
 #define SC_NT_MIXED_UNPACK 0
 #endif
 template <int B, int MODE, int U, int BS, int PF = 0, int LS = 0>
-__global__ __launch_bounds__(BS) void k_unpack_fast(UnpackArgs a, uint32_t nwg = 0, uint32_t dist = 0, uint32_t dist2 = 0) {
+__global__ __launch_bounds__(BS) void k_unpack_fast(UnpackArgs a, uint32_t nwg = 0, uint32_t dist = 0) {
   static_assert(LS == 0 || (B >= 0 && MODE == MODE_PLAIN), "wide layouts: uniform width, plain coding");
   __shared__ u32x4 lds[BS / 64][2][33];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -461,26 +461,28 @@ __global__ __launch_bounds__(BS) void k_unpack_fast(UnpackArgs a, uint32_t nwg =
 
   size_t tile = blockIdx.x;
   if constexpr (PF > 0) {
-    static_assert(B > 0, "prefetch groups are for uniform widths");
+    static_assert(B != 0, "nothing to prefetch for zero-width blocks");
     const uint32_t group = blockIdx.x / (PF + 1), r = blockIdx.x - group * (PF + 1);
     if (r == 0) {
-      // groups [t0, t1): two per prefetcher while the distance ramps up from the start of the array, one after.
-      // dist2 (0: none) is a second, nearer distance: the same bytes are touched again closer to their use, a cache
-      // hit where the first touch is still resident and the real prefetch where it is not (see prefetch_distance2)
+      // groups [t0, t1): two per prefetcher while the distance ramps up from the start of the array, one after
+      const size_t t0 = (size_t)group + (group + 1 < dist ? group + 1 : dist);
+      const size_t t1 = (size_t)group + 1 + (group + 2 < dist ? group + 2 : dist);
       constexpr size_t GB = (size_t)PF * per_iter;
       const size_t nblk = (size_t)nwg * per_iter;
       u32x4 acc = {0, 0, 0, 0};
-      for (int pass = 0; pass < 2; ++pass) {
-        const uint32_t d = pass ? dist2 : dist;
-        if (d == 0) break;
-        const size_t t0 = (size_t)group + (group + 1 < d ? group + 1 : d);
-        const size_t t1 = (size_t)group + 1 + (group + 2 < d ? group + 2 : d);
-        for (size_t t = t0; t < t1; ++t) {
-          if (t * GB >= nblk) break;
+      for (size_t t = t0; t < t1; ++t) {
+        if (t * GB >= nblk) break;
+        if constexpr (B > 0) {
           touch_bytes<BS, GB * B * 16>(a.payload, t * GB * B * 16, nblk * B * 16 - 1, acc);
           // (no seed array: the same bytes of the payload are touched instead, which keeps this path free of branches)
           if constexpr (MODE != MODE_PLAIN)
             touch_bytes<BS, GB * 4>(a.seeds ? static_cast<const void *>(a.seeds) : a.payload, t * GB * 4, nblk * 4 - 1, acc);
+        } else {
+          // per-block widths: the metadata only (widths, payload offsets, seeds), so that the decode waves' first
+          // round of loads hits the cache; the payload's place is not known here
+          touch_bytes<BS, GB>(a.bits, t * GB, nblk - 1, acc);
+          touch_bytes<BS, GB * 8>(a.off, t * GB * 8, nblk * 8 - 1, acc);
+          if constexpr (MODE != MODE_PLAIN) touch_bytes<BS, GB * 4>(a.seeds, t * GB * 4, nblk * 4 - 1, acc);
         }
       }
       asm volatile("" ::"v"(acc));  // keeps the loads; the only wait of this workgroup
@@ -1123,9 +1125,12 @@ constexpr int unpack_steps(int b) { return b >= SC_UW_MINB ? SC_UW_U : (b < 0 ? 
 // (one per 16 decode workgroups, 20 MiB of output ahead: the plateau of a
 // sweep over group size 8..512 and distance 4..64 MiB); from 8 bits on the
 // payload is a large enough share of the traffic that the extra reads cost
-// more than the latency they hide.  The per-block-width decoder does not gain
-// either: its prefetcher has to chase offsets itself and its scattered touches
-// cost more than they save.
+// more than the latency they hide.  b = 1 is sharper than the others: on most boxes its rate
+// peaks at 10 MiB (72 / 79 / 81 / 82 / 81 / 79 / 77 / 76 % at 4 / 6 / 8 / 10 / 12 / 14 / 16 / 20 MiB), on the
+// others it runs at 85 % at either distance.  The per-block-width decoder cannot prefetch its payload (the
+// prefetcher would have to chase offsets itself, and its scattered touches cost more than they save), but it gains
+// 4-7 % from one prefetcher per 8 decode workgroups that touches the metadata only (widths, offsets, seeds, 10 MiB
+// of output ahead): the decode waves' first round of loads then hits the cache and they wait for HBM once, not twice.
 #ifndef SC_PF_GROUP
 #define SC_PF_GROUP 16
 #endif
@@ -1135,18 +1140,18 @@ constexpr int unpack_steps(int b) { return b >= SC_UW_MINB ? SC_UW_U : (b < 0 ? 
 #ifndef SC_PF_MAXB
 #define SC_PF_MAXB 7
 #endif
-constexpr int unpack_prefetch_group(int b) { return (b >= 1 && b <= SC_PF_MAXB) ? SC_PF_GROUP : 0; }
+#ifndef SC_PF_MIXED
+#define SC_PF_MIXED 8
+#endif
+constexpr int unpack_prefetch_group(int b) { return b < 0 ? SC_PF_MIXED : ((b >= 1 && b <= SC_PF_MAXB) ? SC_PF_GROUP : 0); }
 #ifndef SC_PF_DIST1_MIB
 #define SC_PF_DIST1_MIB 10
 #endif
-constexpr size_t prefetch_distance_bytes(int b) { return (size_t)(b == 1 ? SC_PF_DIST1_MIB : SC_PF_DIST_MIB) << 20; }
-#ifndef SC_PF_DIST2_MIB
-#define SC_PF_DIST2_MIB 0
+#ifndef SC_PF_DISTM_MIB
+#define SC_PF_DISTM_MIB 10
 #endif
-#ifndef SC_PF_DIST2_MAXB
-#define SC_PF_DIST2_MAXB 1
-#endif
-constexpr size_t prefetch_distance2_bytes(int b) { return (size_t)(b <= SC_PF_DIST2_MAXB ? SC_PF_DIST2_MIB : 0) << 20; }
+constexpr size_t prefetch_distance_bytes(int b) { return (size_t)(b < 0 ? SC_PF_DISTM_MIB : (b == 1 ? SC_PF_DIST1_MIB : SC_PF_DIST_MIB)) << 20; }
+
 // The encoders read 512 bytes per block whatever the width.  Shapes from sweeps at 2^30 integers with non-temporal
 // input loads and payload stores (64 / 128 / 256 threads x 1 / 2 / 4 steps): 128 x 2 for b <= 12 and b = 16 (b = 8:
 // 74 -> 83 % against 256 x 1), 256 x 1 for the other widths, 256 x 2 for per-block widths.
@@ -1179,9 +1184,8 @@ static size_t launch_unpack_fast(const UnpackArgs &a, hipStream_t st) {
   if constexpr (PF > 0) {
     const size_t groups = (nwg + PF - 1) / PF;
     const size_t dist = prefetch_distance_bytes(BP1 - 1) / (PF * per_wg * 512);
-    const size_t dist2 = prefetch_distance2_bytes(BP1 - 1) / (PF * per_wg * 512);
     hipLaunchKernelGGL((k_unpack_fast<BP1 - 1, MODE, U, BS, PF, LS>), dim3((unsigned)(groups * (PF + 1))), dim3(BS), 0, st, a,
-                       (uint32_t)nwg, (uint32_t)dist, (uint32_t)dist2);
+                       (uint32_t)nwg, (uint32_t)dist);
   } else {
     hipLaunchKernelGGL((k_unpack_fast<BP1 - 1, MODE, U, BS, 0, LS>), dim3((unsigned)nwg), dim3(BS), 0, st, a, 0u, 0u);
   }
