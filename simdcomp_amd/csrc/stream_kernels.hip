@@ -42,33 +42,43 @@ constexpr int SUMS_U = SC_SUMS_U;
 __global__ __launch_bounds__(256) void k_block_sums(const uint8_t *payload, const uint64_t *off, const uint8_t *bits,
                                                     size_t nblocks, uint32_t stream_layout, uint32_t *sums) {
   __shared__ u32x4 lds[4][2][33];
+  __shared__ uint32_t gathered[4][2 * SUMS_U];
   constexpr int U = SUMS_U;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int h = lane >> 5, k = lane & 31;
   u32x4 *slot = lds[wv][h];
-  uint32_t b[U];
-  uint64_t o[U];
+  uint32_t b[U], o[U];
   u32x4 ld[U];
-  // widths and offsets of the wave's 2 * U consecutive blocks: one coalesced load per array, handed to the half-waves
-  // through scalar registers (blocks past the end repeat the last one)
+  uintptr_t first_payload;
+  // widths and offsets of the wave's 2 * U consecutive blocks: one coalesced load per array (blocks past the end
+  // repeat the last one), handed to the half-waves through the LDS crossbar: this kernel is bound by vector-ALU
+  // work, and a ds_bpermute costs it one instruction where the scalar hand-out of the decoders costs four.  The
+  // offsets travel as 32-bit distances from the wave's first block (16 blocks span at most 8 KiB)
   constexpr int NB = 2 * U;
   const size_t wb = ((size_t)blockIdx.x * 4 + wv) * NB;
   {
     const size_t mine = wb + (size_t)(lane % NB) < nblocks ? wb + (size_t)(lane % NB) : nblocks - 1;
     const uint32_t mb = bits[mine];
     const uint64_t mo = off[mine] + (stream_layout ? mine + 1 : 0);
-    hand_out<U>(mb, h, b);
-    hand_out<U>(mo, h, o);
+    const uint64_t mo0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(mo >> 32)) << 32) |
+                         (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)mo);
+    first_payload = reinterpret_cast<uintptr_t>(payload) + mo0;
+    const uint32_t rel = (uint32_t)(mo - mo0);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int from = 4 * (2 * u + h);  // byte address of the source lane
+      b[u] = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)mb);
+      o[u] = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)rel);
+    }
   }
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     b[u] = b[u] > 32 ? 32 : b[u];
     const uint32_t last = b[u] ? b[u] - 1 : 0;
-    uintptr_t at = reinterpret_cast<uintptr_t>(payload) + o[u] + 16 * ((uint32_t)k < last ? (uint32_t)k : last);
+    uintptr_t at = first_payload + (o[u] + 16 * ((uint32_t)k < last ? (uint32_t)k : last));
     at = (uint32_t)k > last ? (at & ~(uintptr_t)15) : at;  // idle lanes: an aligned address coalesces better
-    ld[u] = SC_NT_SUMS ? load_global_nt(b[u] ? at : reinterpret_cast<uintptr_t>(sums)) : load_global_at(b[u] ? at : reinterpret_cast<uintptr_t>(sums));
+    ld[u] = load_global_at(b[u] ? at : reinterpret_cast<uintptr_t>(sums));
   }
-  uint32_t mine_out = 0;
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     wave_lds_fence();
@@ -84,11 +94,11 @@ __global__ __launch_bounds__(256) void k_block_sums(const uint8_t *payload, cons
     v.w = funnel(hi.w, lo.w, s) & m;
     const uint32_t total = half_scan_add(v.x + v.y + v.z + v.w);  // lane 31 of the half-wave: the block's sum
     const uint32_t res = b[u] == 32 ? v.w : total;
-    // gathered into lanes 0 .. 2U-1 for one coalesced store
-    const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)res, 31), r1 = (uint32_t)__builtin_amdgcn_readlane((int)res, 63);
-    mine_out = lane == 2 * u ? r0 : (lane == 2 * u + 1 ? r1 : mine_out);
+    // the last lane of each half-wave leaves the result in LDS, for one coalesced store at the end
+    if (k == 31) gathered[wv][2 * u + h] = res;
   }
-  if (lane < NB && wb + (size_t)lane < nblocks) sums[wb + (size_t)lane] = mine_out;
+  wave_lds_fence();
+  if (lane < NB && wb + (size_t)lane < nblocks) sums[wb + (size_t)lane] = gathered[wv][lane];
 }
 
 // (restart flag << 32) | value
