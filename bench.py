@@ -103,6 +103,28 @@ def launch_ranks(a, argv):
     return rc
 
 
+_REAL_STDOUT = None
+
+
+def keep_stdout_for_the_line():
+    """Libraries loaded below write to file descriptor 1 as well (RCCL prints a version banner when the process group
+    comes up): from here on everything written to stdout goes to stderr, and only print_line() reaches the real
+    stdout, so that rank 0 prints exactly one JSON line there."""
+    global _REAL_STDOUT
+    sys.stdout.flush()
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
+
+
+def print_line(obj):
+    data = (json.dumps(obj) + "\n").encode()
+    if _REAL_STDOUT is None:
+        sys.stdout.write(data.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_REAL_STDOUT, data)
+
+
 def selftest(a, rank, world):
     """The multi-rank plumbing without a GPU: gloo process group, block-range shards from the library's partitioner,
     a host checksum per shard, and the verification all-reduce.  Rank 0 prints one JSON line."""
@@ -119,8 +141,8 @@ def selftest(a, rank, world):
     dist.all_reduce(acc, op=dist.ReduceOp.SUM)
     if rank == 0:
         got = acc.tolist()
-        print(json.dumps({"selftest": True, "backend": "gloo", "n_gpus": dist.get_world_size(), "blocks": got[3],
-                          "sum_of_first": got[2], "checksum": ((got[0] << 32) + got[1]) & (2 ** 64 - 1)}), flush=True)
+        print_line({"selftest": True, "backend": "gloo", "n_gpus": dist.get_world_size(), "blocks": got[3],
+                    "sum_of_first": got[2], "checksum": ((got[0] << 32) + got[1]) & (2 ** 64 - 1)})
     dist.barrier()
     dist.destroy_process_group()
 
@@ -606,6 +628,7 @@ def main():
         # plain `python bench.py --gpus N`: become the launcher (nothing below runs in this process)
         sys.exit(launch_ranks(a, sys.argv[1:]))
 
+    keep_stdout_for_the_line()
     load_package()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -757,7 +780,7 @@ def main():
         if rank == 0:
             line["host_to_host"] = h2h
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        print_line(line)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
