@@ -558,7 +558,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void k_index_emit(const uint8_t *stre
   uint64_t r = ce >> 16;
   // Memory operations of a wave complete in order, so a width byte requested behind the stores of the previous
   // record would wait for them as well: eight records are walked first (eight dependent loads), then written.
-  constexpr int BATCH = 8;
+  constexpr int BATCH = 8;  // (the packed width bytes below fill one 64-bit word)
   bool ok = true;
   while (ok && p < end) {
     size_t ps[BATCH];
@@ -580,11 +580,26 @@ __global__ __launch_bounds__(EMIT_THREADS) void k_index_emit(const uint8_t *stre
         }
       }
     }
+    if (n == BATCH && r + BATCH <= max_blocks) {
+      // a full batch leaves as four 16-byte stores and one 8-byte store (at whatever alignment r gives them)
+      // instead of sixteen single stores
+      typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+      typedef u64x2 u64x2_u __attribute__((aligned(1)));
+      typedef uint64_t u64_u __attribute__((aligned(1)));
+      uint64_t packed = 0;
 #pragma unroll
-    for (int i = 0; i < BATCH; ++i) {
-      if (i < n && r + i < max_blocks) {
-        bits[r + i] = (uint8_t)bs[i];
-        off[r + i] = ps[i] - (r + i);
+      for (int i = 0; i < BATCH; ++i) packed |= (uint64_t)bs[i] << (8 * i);
+      *reinterpret_cast<u64_u *>(bits + r) = packed;
+#pragma unroll
+      for (int i = 0; i < BATCH; i += 2)
+        *reinterpret_cast<u64x2_u *>(off + r + i) = u64x2{ps[i] - (r + i), ps[i + 1] - (r + i + 1)};
+    } else {
+#pragma unroll
+      for (int i = 0; i < BATCH; ++i) {
+        if (i < n && r + i < max_blocks) {
+          bits[r + i] = (uint8_t)bs[i];
+          off[r + i] = ps[i] - (r + i);
+        }
       }
     }
     r += n;
