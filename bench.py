@@ -31,6 +31,11 @@ Extra objects on the JSON line:
                 on a mixed-width corpus; round trip and answers checked in place;
   host_to_host  the same decode including pinned H2D/D2H copies, at four uniform
                 widths and on a mixed-width (1..20 bits) corpus.
+roofline.traffic is measured in the same run at N = 1: after its own work rank 0
+starts this script twice more as a child process under `rocprofv3 --pmc`
+(FETCH_SIZE, WRITE_SIZE; one step each) and averages the counters of the 32 decode
+launches (--no-traffic skips it; the committed summary of an earlier run,
+profiles/pmc_traffic_latest.json, is the fallback when the profiler is missing).
 `encode` and `host_to_host` run on every rank at the same time (each GPU has its
 own PCIe link; host memory is shared) and are reported per rank and summed;
 cpu_baseline and callers run at N = 1 only.
@@ -254,6 +259,69 @@ def measured_traffic(nblocks):
         return sum(r["hbm_bytes"] for r in rows) / len(rows)
     except Exception:
         return None
+
+
+def live_traffic(log2n, nblocks):
+    """HBM bytes per launch of the decode kernel measured NOW: this same script is run twice more as a child
+    process under `rocprofv3 --pmc` (FETCH_SIZE, then WRITE_SIZE: the two do not fit one pass on gfx950), one step
+    each, and the counters of the 32 decode launches are averaged.  Read bytes = 2 x FETCH_SIZE x 1024 (gfx950 tallies
+    128-byte read requests as 64 bytes), written bytes = WRITE_SIZE x 1024.  Returns (bytes, per-width table) or
+    (None, reason)."""
+    import csv
+    import glob
+    import re
+    import shutil
+    import tempfile
+
+    tool = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(tool):
+        return None, "rocprofv3 not found"
+    pat = re.compile(r"k_unpack_fast<(\d+), 1, ")
+    per = {}
+    tmp = tempfile.mkdtemp(prefix="simdcomp_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, ctr)
+            cmd = [tool, "--pmc", ctr, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
+                   "--steps", "1", "--warmup", "0", "--log2n", str(log2n), "--no-cpu", "--no-h2h", "--no-callers", "--no-encode",
+                   "--no-traffic"]
+            child = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                     start_new_session=True)
+            try:
+                rc = child.wait(timeout=150)
+            except subprocess.TimeoutExpired:
+                import signal
+
+                os.killpg(child.pid, signal.SIGKILL)  # the profiler and the run under it: the group started here
+                child.wait()
+                return None, f"rocprofv3 --pmc {ctr} timed out"
+            if rc != 0:
+                return None, f"rocprofv3 --pmc {ctr} exited with {rc}"
+            files = glob.glob(out + "/**/*counter_collection.csv", recursive=True)
+            if not files:
+                return None, f"rocprofv3 --pmc {ctr} wrote no counter file"
+            sums = {}
+            for row in csv.DictReader(open(files[0])):
+                m = pat.search(row["Kernel_Name"])
+                if m and row["Counter_Name"] == ctr:
+                    key = (int(m.group(1)), row["Dispatch_Id"])
+                    sums[key] = sums.get(key, 0.0) + float(row["Counter_Value"])
+            for (b, _), v in sums.items():  # the last dispatch of a width is the timed step's
+                per.setdefault(b, {})[ctr] = v
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    table = {}
+    for b in WIDTHS:
+        if b not in per or len(per[b]) != 2:
+            return None, f"no counters for width {b}"
+        if abs(per[b]["WRITE_SIZE"] * 1024 - nblocks * 512) > nblocks * 8:
+            return None, "written bytes do not match the corpus size"
+        table[str(b)] = {"FETCH_SIZE_KB": per[b]["FETCH_SIZE"], "WRITE_SIZE_KB": per[b]["WRITE_SIZE"],
+                         "hbm_bytes": int(2 * per[b]["FETCH_SIZE"] * 1024 + per[b]["WRITE_SIZE"] * 1024)}
+    return sum(v["hbm_bytes"] for v in table.values()) / len(table), table
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -621,6 +689,7 @@ def main():
     ap.add_argument("--no-h2h", action="store_true", help="skip the host-to-host leg")
     ap.add_argument("--no-encode", action="store_true", help="skip the encoder leg")
     ap.add_argument("--no-callers", action="store_true", help="skip the stream / search leg")
+    ap.add_argument("--no-traffic", action="store_true", help="do not re-run under rocprofv3 --pmc for roofline.traffic")
     ap.add_argument("--selftest", action="store_true", help="CPU-only check of the multi-rank plumbing (gloo)")
     a = ap.parse_args()
 
@@ -775,6 +844,18 @@ def main():
     if rank == 0 and not a.no_callers and world == 1:
         line["callers"] = callers_leg(dev, a.log2n)
         torch.cuda.empty_cache()
+    if rank == 0 and not a.no_traffic and world == 1:
+        # HBM-side traffic of the decode kernel from the hardware counters, measured in this run (two child runs of
+        # this script under rocprofv3 --pmc); the committed summary of an earlier run stays as the fallback
+        live, detail = live_traffic(a.log2n, nblocks)
+        if live is not None:
+            line["roofline"]["traffic"] = live
+            line["roofline"]["traffic_source"] = ("measured in this run: this script re-run twice as a child under rocprofv3 --pmc "
+                                                  "(FETCH_SIZE, WRITE_SIZE; one step each), average over the 32 decode launches")
+            line["roofline"]["traffic_over_algorithmic"] = round(live / line["roofline"]["algorithmic_bytes_per_launch"], 4)
+            line["roofline"]["traffic_per_width"] = {b: v["hbm_bytes"] for b, v in detail.items()}
+        else:
+            line["roofline"]["traffic_live_failed"] = detail
     if not a.no_h2h:
         h2h = host_to_host(dev, barrier, distributed)
         if rank == 0:
