@@ -261,7 +261,7 @@ def measured_traffic(nblocks):
         return None
 
 
-def live_traffic(log2n, nblocks):
+def live_traffic(log2n, nblocks, with_encode):
     """HBM bytes per launch of the decode kernel measured NOW: this same script is run twice more as a child
     process under `rocprofv3 --pmc` (FETCH_SIZE, then WRITE_SIZE: the two do not fit one pass on gfx950), one step
     each, and the counters of the 32 decode launches are averaged.  Read bytes = 2 x FETCH_SIZE x 1024 (gfx950 tallies
@@ -277,7 +277,8 @@ def live_traffic(log2n, nblocks):
     if not os.path.exists(tool):
         return None, "rocprofv3 not found"
     pat = re.compile(r"k_unpack_fast<(\d+), 1, ")
-    per = {}
+    pat_enc = re.compile(r"k_pack_fast<(\d+), 1, false")
+    per, enc = {}, {}
     tmp = tempfile.mkdtemp(prefix="simdcomp_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "TORCHELASTIC_RUN_ID"):
@@ -286,8 +287,9 @@ def live_traffic(log2n, nblocks):
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(tmp, ctr)
             cmd = [tool, "--pmc", ctr, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
-                   "--steps", "1", "--warmup", "0", "--log2n", str(log2n), "--no-cpu", "--no-h2h", "--no-callers", "--no-encode",
-                   "--no-traffic"]
+                   "--steps", "1", "--warmup", "0", "--log2n", str(log2n), "--no-cpu", "--no-h2h", "--no-callers", "--no-traffic"]
+            if not with_encode:
+                cmd.append("--no-encode")
             child = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
                                      start_new_session=True)
             try:
@@ -303,14 +305,22 @@ def live_traffic(log2n, nblocks):
             files = glob.glob(out + "/**/*counter_collection.csv", recursive=True)
             if not files:
                 return None, f"rocprofv3 --pmc {ctr} wrote no counter file"
-            sums = {}
+            sums, esums = {}, {}
             for row in csv.DictReader(open(files[0])):
+                if row["Counter_Name"] != ctr:
+                    continue
                 m = pat.search(row["Kernel_Name"])
-                if m and row["Counter_Name"] == ctr:
+                if m:
                     key = (int(m.group(1)), row["Dispatch_Id"])
                     sums[key] = sums.get(key, 0.0) + float(row["Counter_Value"])
+                m = pat_enc.search(row["Kernel_Name"])
+                if m:
+                    key = (int(m.group(1)), row["Dispatch_Id"])
+                    esums[key] = esums.get(key, 0.0) + float(row["Counter_Value"])
             for (b, _), v in sums.items():  # the last dispatch of a width is the timed step's
                 per.setdefault(b, {})[ctr] = v
+            for (b, _), v in esums.items():  # encoder launches of a width all move the same bytes
+                enc.setdefault(b, {})[ctr] = v
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     table = {}
@@ -321,7 +331,9 @@ def live_traffic(log2n, nblocks):
             return None, "written bytes do not match the corpus size"
         table[str(b)] = {"FETCH_SIZE_KB": per[b]["FETCH_SIZE"], "WRITE_SIZE_KB": per[b]["WRITE_SIZE"],
                          "hbm_bytes": int(2 * per[b]["FETCH_SIZE"] * 1024 + per[b]["WRITE_SIZE"] * 1024)}
-    return sum(v["hbm_bytes"] for v in table.values()) / len(table), table
+    enc_table = {str(b): int(2 * enc[b]["FETCH_SIZE"] * 1024 + enc[b]["WRITE_SIZE"] * 1024) for b in WIDTHS
+                 if b in enc and len(enc[b]) == 2}
+    return sum(v["hbm_bytes"] for v in table.values()) / len(table), {"decode": table, "encode": enc_table}
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -847,13 +859,18 @@ def main():
     if rank == 0 and not a.no_traffic and world == 1:
         # HBM-side traffic of the decode kernel from the hardware counters, measured in this run (two child runs of
         # this script under rocprofv3 --pmc); the committed summary of an earlier run stays as the fallback
-        live, detail = live_traffic(a.log2n, nblocks)
+        live, detail = live_traffic(a.log2n, nblocks, not a.no_encode)
         if live is not None:
             line["roofline"]["traffic"] = live
             line["roofline"]["traffic_source"] = ("measured in this run: this script re-run twice as a child under rocprofv3 --pmc "
                                                   "(FETCH_SIZE, WRITE_SIZE; one step each), average over the 32 decode launches")
             line["roofline"]["traffic_over_algorithmic"] = round(live / line["roofline"]["algorithmic_bytes_per_launch"], 4)
-            line["roofline"]["traffic_per_width"] = {b: v["hbm_bytes"] for b, v in detail.items()}
+            line["roofline"]["traffic_per_width"] = {b: v["hbm_bytes"] for b, v in detail["decode"].items()}
+            if "encode" in line and len(detail["encode"]) == len(WIDTHS):
+                et = detail["encode"]
+                line["encode"]["traffic"] = sum(et.values()) / len(et)
+                line["encode"]["traffic_over_algorithmic"] = round(sum(et.values()) / sum(algorithmic_bytes(nblocks, b) for b in WIDTHS), 4)
+                line["encode"]["traffic_per_width"] = et
         else:
             line["roofline"]["traffic_live_failed"] = detail
     if not a.no_h2h:
