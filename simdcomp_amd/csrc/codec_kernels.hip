@@ -441,10 +441,11 @@ __device__ __forceinline__ void touch_bytes(const void *base, size_t byte0, size
 
 // LS > 0: the wide layouts (2^LS four-lane groups per block, see UnpackArgs::lane_groups): group g of wide block W is
 // "block" W * 2^LS + g here, its payload vectors and output rows 2^LS apart.  Uniform widths, plain coding only.
-// From 24 bits on the payload is read with non-temporal loads: it is nearly half of the traffic there and read
-// once, and keeping it out of the caches' way measured +2..+4 points of HBM peak for b = 26..32 (neutral below).
+// From 20 bits on the payload is read with non-temporal loads: it is 40-50 % of the traffic there and read
+// once, and keeping it out of the caches' way measured +2..+4 points of HBM peak for b = 26..32 and, together with
+// 256 threads per workgroup, +1 point and steadier rates for b = 20..25 (neutral below 20).
 #ifndef SC_NT_PAYLOAD_MINB
-#define SC_NT_PAYLOAD_MINB 24
+#define SC_NT_PAYLOAD_MINB 20
 #endif
 #ifndef SC_NT_MIXED_UNPACK
 #define SC_NT_MIXED_UNPACK 0
@@ -1102,7 +1103,7 @@ constexpr int REDUCE_U = SC_REDUCE_U;
 // at every width with 2^30 integers: the best shapes write 4 KiB (narrow
 // widths, which are almost pure store traffic and need two blocks per half-wave
 // to cover the payload read in front of the stores) or 2 KiB per workgroup;
-// very wide blocks prefer 256 threads.  The per-block-width kernels chase two
+// blocks of 20 bits and more prefer 256 threads.  The per-block-width kernels chase two
 // dependent loads (offset, then payload) and measured best with four steps.
 #ifndef SC_UN_BS
 #define SC_UN_BS 128
@@ -1116,11 +1117,17 @@ constexpr int REDUCE_U = SC_REDUCE_U;
 #define SC_UW_BS 256
 #define SC_UW_U 1
 #endif
-constexpr int unpack_threads(int b) { return b >= SC_UW_MINB ? SC_UW_BS : ((b < 0 || b >= 28) ? 256 : ((b >= 1 && b <= SC_UN_MAXB) ? SC_UN_BS : 128)); }
+#ifndef SC_UM_LO
+#define SC_UM_LO 99
+#define SC_UM_HI 0
+#define SC_UM_BS 128
+#define SC_UM_U 1
+#endif
+constexpr int unpack_threads(int b) { return (b >= SC_UM_LO && b <= SC_UM_HI) ? SC_UM_BS : b >= SC_UW_MINB ? SC_UW_BS : ((b < 0 || b >= 20) ? 256 : ((b >= 1 && b <= SC_UN_MAXB) ? SC_UN_BS : 128)); }
 #ifndef SC_MIXED_UNPACK_STEPS
 #define SC_MIXED_UNPACK_STEPS 4
 #endif
-constexpr int unpack_steps(int b) { return b >= SC_UW_MINB ? SC_UW_U : (b < 0 ? SC_MIXED_UNPACK_STEPS : ((b >= 1 && b <= SC_UN_MAXB) ? SC_UN_U : (b <= 14 ? 2 : 1))); }
+constexpr int unpack_steps(int b) { return (b >= SC_UM_LO && b <= SC_UM_HI) ? SC_UM_U : b >= SC_UW_MINB ? SC_UW_U : (b < 0 ? SC_MIXED_UNPACK_STEPS : ((b >= 1 && b <= SC_UN_MAXB) ? SC_UN_U : (b <= 14 ? 2 : 1))); }
 // Widths 1..7 gain 3-17 points of HBM peak from dedicated prefetch workgroups
 // (one per 16 decode workgroups, 20 MiB of output ahead: the plateau of a
 // sweep over group size 8..512 and distance 4..64 MiB); from 8 bits on the
