@@ -1150,14 +1150,20 @@ constexpr int unpack_steps(int b) { return (b >= SC_UM_LO && b <= SC_UM_HI) ? SC
 #ifndef SC_PF_MIXED
 #define SC_PF_MIXED 8
 #endif
-constexpr int unpack_prefetch_group(int b) { return b < 0 ? SC_PF_MIXED : ((b >= 1 && b <= SC_PF_MAXB) ? SC_PF_GROUP : 0); }
+// (b = 5..7: one prefetcher per 24 decode workgroups, +1 point; 40 and more lose 3-5 points, as do 10 and 40 MiB)
+#ifndef SC_PF_HI_MINB
+#define SC_PF_HI_MINB 5
+#define SC_PF_GROUP_HI 24
+#define SC_PF_DIST_HI_MIB 20
+#endif
+constexpr int unpack_prefetch_group(int b) { return b < 0 ? SC_PF_MIXED : ((b >= 1 && b <= SC_PF_MAXB) ? (b >= SC_PF_HI_MINB ? SC_PF_GROUP_HI : SC_PF_GROUP) : 0); }
 #ifndef SC_PF_DIST1_MIB
 #define SC_PF_DIST1_MIB 10
 #endif
 #ifndef SC_PF_DISTM_MIB
 #define SC_PF_DISTM_MIB 10
 #endif
-constexpr size_t prefetch_distance_bytes(int b) { return (size_t)(b < 0 ? SC_PF_DISTM_MIB : (b == 1 ? SC_PF_DIST1_MIB : SC_PF_DIST_MIB)) << 20; }
+constexpr size_t prefetch_distance_bytes(int b) { return (size_t)(b < 0 ? SC_PF_DISTM_MIB : (b == 1 ? SC_PF_DIST1_MIB : (b >= SC_PF_HI_MINB ? SC_PF_DIST_HI_MIB : SC_PF_DIST_MIB))) << 20; }
 
 // The encoders read 512 bytes per block whatever the width.  Shapes from sweeps at 2^30 integers with non-temporal
 // input loads and payload stores (64 / 128 / 256 threads x 1 / 2 / 4 steps): 128 x 2 for b <= 12 and b = 16 (b = 8:
