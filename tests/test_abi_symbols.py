@@ -172,3 +172,27 @@ def test_fastsetd1(orc, ref, bit):
         mine = oracle.aligned_copy(base)
         lib.simdfastsetd1fromprevious(mine.ctypes.data, bit, prev, newv, idx)
         assert np.array_equal(mine, theirs)
+
+
+def test_public_headers_compile_as_plain_c_and_cxx(tmp_path):
+    """include/simdcomp.h and include/simdcomp_hip.h are what a host language binds: they have to go through a C89
+    compiler in pedantic mode (the reference is C89, Makefile:8) and through a C++ compiler, with no HIP header."""
+    import shutil
+    import subprocess
+
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    src = '#include "simdcomp.h"\n#include "simdcomp_hip.h"\nint main(void) { return 0; }\n'
+    c = tmp_path / "h.c"
+    c.write_text(src)
+    cc = shutil.which("gcc") or shutil.which("cc")
+    assert cc, "no C compiler"
+    for std in ("c89", "c99", "c11"):
+        r = subprocess.run([cc, "-std=" + std, "-pedantic", "-Wall", "-Werror", "-I", inc, "-fsyntax-only", str(c)],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, (std, r.stderr)
+    cxx = shutil.which("g++") or shutil.which("c++")
+    if cxx:
+        cpp = tmp_path / "h.cpp"
+        cpp.write_text(src)
+        r = subprocess.run([cxx, "-std=c++11", "-Wall", "-Werror", "-I", inc, "-fsyntax-only", str(cpp)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
