@@ -314,121 +314,219 @@ hipError_t launch_stream_unbuild(const uint8_t *stream, const uint64_t *off, con
 #endif
 constexpr int IDX_CHUNK = SC_IDX_CHUNK;
 constexpr int IDX_CAND = 513;
-constexpr int IDX_THREADS = 256;
 constexpr int IDX_GROUP = 32;  // chunks per group
 constexpr int IDX_SUPER = 32;  // groups per super-group
 constexpr uint32_t IDX_INVALID = 0xFFFFFFFFu;
 constexpr uint64_t IDX_INVALID64 = ~0ull;
 
-// Stage len bytes from stream + c0 in LDS: whole 16-byte vectors (at whatever byte address they start), then the
-// last few bytes one by one so that nothing past the end of the stream is read.
-template <int THREADS>
-__device__ __forceinline__ const uint8_t *stage_chunk(const uint8_t *stream, size_t c0, uint32_t len, u32x4 *sh) {
-  const uint8_t *src = stream + c0;
-  const uint32_t nvec = len / 16;
-  uint32_t i = threadIdx.x;
-  for (; i + 3 * THREADS < nvec; i += 4 * THREADS) {  // four loads in flight per thread
-    const u32x4 v0 = *reinterpret_cast<const u32x4_u *>(src + 16 * (size_t)i);
-    const u32x4 v1 = *reinterpret_cast<const u32x4_u *>(src + 16 * (size_t)(i + THREADS));
-    const u32x4 v2 = *reinterpret_cast<const u32x4_u *>(src + 16 * (size_t)(i + 2 * THREADS));
-    const u32x4 v3 = *reinterpret_cast<const u32x4_u *>(src + 16 * (size_t)(i + 3 * THREADS));
-    sh[i] = v0;
-    sh[i + THREADS] = v1;
-    sh[i + 2 * THREADS] = v2;
-    sh[i + 3 * THREADS] = v3;
-  }
-  for (; i < nvec; i += THREADS) sh[i] = *reinterpret_cast<const u32x4_u *>(src + 16 * (size_t)i);
-  uint8_t *bytes = reinterpret_cast<uint8_t *>(sh);
-  for (uint32_t j = 16 * nvec + threadIdx.x; j < len; j += THREADS) bytes[j] = src[j];
-  __syncthreads();
-  return bytes;
-}
-
 // Kernel A.  Candidate f's walk goes through byte f + 1 + 16*b(f); when that is again one of the 513 candidates the
 // rest of the walk is that candidate's, so only "roots" (candidates whose first step already leaves the candidate
-// window) walk through the chunk; the others are linked to their successor and resolved by ten rounds of pointer
-// jumping over the 513 entries.  res[] words: (records << 16) | target, target < 1024: continue at that candidate,
-// target >= 1024: done, the walk left the chunk target - 1024 bytes into the next one.
+// window) walk on; the others are linked to their successor and resolved by ten rounds of pointer jumping over the
+// 513 entries.  Only the first 513 * IDX_PROBE bytes of the chunk are staged in LDS: a root walks until it crosses
+// that boundary, which is where nearly all false candidates die (a payload byte is a valid width byte several times
+// in a row only rarely) and where walks that have met the true chain on the way arrive at the same byte.  A root that
+// crosses the boundary is a "survivor": survivors arriving at the same byte share one of the chunk's IDX_SLOTS slots,
+// kernel A' walks each slot to the end of the chunk (one lane per slot, all chunks of the stream at once), and the
+// table keeps (records so far, slot) for the candidates that end in a slot.
+// res[] words: (records << 16) | target, target < 1024: continue at that candidate, 1024 <= target < 0x8000: done, the
+// walk left the chunk target - 1024 bytes into the next one, target >= 0x8000: continues in slot target - 0x8000.
 constexpr uint32_t IDX_DONE = 1024;
+constexpr uint32_t IDX_PENDING = 0x8000;
+#ifndef SC_IDX_SLOTS
+#define SC_IDX_SLOTS 4
+#endif
+#ifndef SC_IDX_PROBE
+#define SC_IDX_PROBE 4
+#endif
+constexpr int IDX_SLOTS = SC_IDX_SLOTS;
+constexpr int IDX_PROBE = SC_IDX_PROBE;
+constexpr int CAND_THREADS = 64;
 
-__global__ __launch_bounds__(IDX_THREADS) void k_index_candidates(const uint8_t *stream, size_t nbytes, uint32_t *table) {
-  __shared__ u32x4 sh[IDX_CHUNK / 16];
+__global__ __launch_bounds__(CAND_THREADS) void k_index_candidates(const uint8_t *stream, size_t nbytes, uint32_t *table,
+                                                                   uint32_t *slot_start) {
+  constexpr uint32_t BOUNDARY = IDX_CAND * IDX_PROBE;  // roots walk until they cross this byte
+  constexpr uint32_t WINDOW = BOUNDARY;                // so this much of the chunk is staged
+  __shared__ u32x4 window[(WINDOW + 15) / 16];
   __shared__ uint32_t res[IDX_CAND];
   __shared__ uint16_t roots[IDX_CAND];
-  __shared__ uint32_t nroots;
+  __shared__ uint16_t links[IDX_CAND];
   const size_t c0 = (size_t)blockIdx.x * IDX_CHUNK;
+  const uint8_t *src = stream + c0;
   const uint32_t len = (uint32_t)(nbytes - c0 < (size_t)IDX_CHUNK ? nbytes - c0 : (size_t)IDX_CHUNK);
-  if (threadIdx.x == 0) nroots = 0;
-  const uint8_t *by = stage_chunk<IDX_THREADS>(stream, c0, len, sh);
-  for (uint32_t f = threadIdx.x; f < IDX_CAND; f += IDX_THREADS) {
-    uint32_t word;
-    if (f >= len) {
-      word = IDX_DONE + (f - len);  // the chunk is shorter than the candidate window
-    } else {
-      const uint32_t b = by[f];
-      const uint32_t nf = f + 1 + 16 * b;
-      if (b > 32) {
-        word = IDX_INVALID;
-      } else if (nf < IDX_CAND && nf < len) {
-        word = (1u << 16) | nf;
+  const uint32_t win = len < WINDOW ? len : WINDOW;
+  uint8_t *by = reinterpret_cast<uint8_t *>(window);
+  for (uint32_t i = threadIdx.x; 16 * (i + 1) <= win; i += CAND_THREADS) window[i] = *reinterpret_cast<const u32x4_u *>(src + 16 * i);
+  for (uint32_t j = (win & ~15u) + threadIdx.x; j < win; j += CAND_THREADS) by[j] = src[j];
+  __syncthreads();
+  // the workgroup is one wave: roots and links are gathered into lists with ballots (counts the same in every lane)
+  const uint64_t below = (1ull << threadIdx.x) - 1;
+  uint32_t total = 0, nlinks = 0;
+  for (uint32_t f = threadIdx.x; f < IDX_CAND + CAND_THREADS - 1; f += CAND_THREADS) {
+    uint32_t word = IDX_INVALID;
+    bool root = false, link = false;
+    if (f < IDX_CAND) {
+      if (f >= len) {
+        word = IDX_DONE + (f - len);  // the chunk is shorter than the candidate window
       } else {
-        word = IDX_INVALID;  // replaced by the walk below
-        roots[atomicAdd(&nroots, 1u)] = (uint16_t)f;
+        const uint32_t b = by[f];
+        const uint32_t nf = f + 1 + 16 * b;
+        if (b > 32) {
+        } else if (nf >= len) {
+          word = (1u << 16) | (IDX_DONE + nf - len);
+        } else if (nf < IDX_CAND) {
+          word = (1u << 16) | nf;
+          link = true;
+        } else {
+          root = true;  // res[f] comes from the walk below
+        }
       }
+      res[f] = word;
     }
-    res[f] = word;
+    const uint64_t rmask = __ballot(root), lmask = __ballot(link);
+    if (root) roots[total + __popcll(rmask & below)] = (uint16_t)f;
+    if (link) links[nlinks + __popcll(lmask & below)] = (uint16_t)f;
+    total += __popcll(rmask);
+    nlinks += __popcll(lmask);
   }
   __syncthreads();
-  // the roots, packed into the first threads so that the other waves do not sit in the loop
-  for (uint32_t t = threadIdx.x; t < nroots; t += IDX_THREADS) {
-    const uint32_t r = roots[t];
+  uint32_t slot_pos[IDX_SLOTS];
+  uint32_t nslots = 0;  // both the same in every lane
+#pragma unroll
+  for (int k = 0; k < IDX_SLOTS; ++k) slot_pos[k] = IDX_INVALID;
+#ifdef SC_DBG_NOROOTS
+  total = 0;
+#endif
+  for (uint32_t base = 0; base < total; base += CAND_THREADS) {
+    const uint32_t t = base + threadIdx.x;
+    const uint32_t r = t < total ? roots[t] : 0;
     uint32_t p = r + 1 + 16 * (uint32_t)by[r], cnt = 1;
-    bool bad = false;
-    while (p < len) {
+    bool walking = t < total, dead = false;
+    while (walking && p < BOUNDARY) {
       const uint32_t bb = by[p];
       if (bb > 32) {
-        bad = true;
-        break;
+        dead = true;
+        walking = false;
+      } else {
+        p += 1 + 16 * bb;
+        ++cnt;
+        walking = p < len;
       }
-      p += 1 + 16 * bb;
-      ++cnt;
     }
-    res[r] = bad ? IDX_INVALID : ((cnt << 16) | (IDX_DONE + p - len));
+    // survivors standing on the same byte have the same future: one slot for all of them
+    int slot = -1;
+    uint64_t todo = __ballot(walking);
+    while (todo) {
+      const int leader = __ffsll((unsigned long long)todo) - 1;
+      const uint32_t lp = __shfl(p, leader);
+      int s = -1;
+#pragma unroll
+      for (int k = 0; k < IDX_SLOTS; ++k)
+        if (slot_pos[k] == lp) s = k;
+      if (s < 0 && nslots < (uint32_t)IDX_SLOTS) {
+        s = (int)nslots++;
+#pragma unroll
+        for (int k = 0; k < IDX_SLOTS; ++k)
+          if (k == s) slot_pos[k] = lp;
+      }
+      const bool same = walking && p == lp;
+      if (same) slot = s;
+      todo &= ~__ballot(same);
+    }
+#ifndef SC_DBG_NOWALK
+    if (walking && slot < 0) {
+      // more distinct survivors than slots (streams made to look like that): this one walks to the end right here
+      while (p < len) {
+        const uint32_t bb = src[p];
+        if (bb > 32) {
+          dead = true;
+          break;
+        }
+        p += 1 + 16 * bb;
+        ++cnt;
+      }
+      walking = false;
+    }
+#endif
+    if (t < total)
+      res[r] = dead ? IDX_INVALID : ((cnt << 16) | (walking ? IDX_PENDING + (uint32_t)slot : IDX_DONE + p - len));
+  }
+  if (threadIdx.x < IDX_SLOTS) {
+    uint32_t v = IDX_INVALID;
+#pragma unroll
+    for (int k = 0; k < IDX_SLOTS; ++k)
+      if ((int)threadIdx.x == k) v = slot_pos[k];
+    slot_start[(size_t)blockIdx.x * IDX_SLOTS + threadIdx.x] = v;
   }
   __syncthreads();
-  constexpr int PER_THREAD = (IDX_CAND + IDX_THREADS - 1) / IDX_THREADS;
-  for (int round = 0; round < 10; ++round) {  // 2^10 >= the longest chain of links (513)
-    uint32_t w[PER_THREAD];
-    bool link[PER_THREAD];
-#pragma unroll
-    for (int i = 0; i < PER_THREAD; ++i) {
-      const uint32_t f = threadIdx.x + i * IDX_THREADS;
-      w[i] = f < IDX_CAND ? res[f] : IDX_INVALID;
-      link[i] = w[i] != IDX_INVALID && (w[i] & 0xFFFF) < IDX_DONE;
-      if (link[i]) {
-        const uint32_t t = res[w[i] & 0xFFFF];
-        w[i] = t == IDX_INVALID ? IDX_INVALID : ((((w[i] >> 16) + (t >> 16)) << 16) | (t & 0xFFFF));
-      }
+  // pointer jumping over the links only; a link whose target is resolved is resolved itself and leaves the list
+#ifdef SC_DBG_NOPJ
+  nlinks = 0;
+#endif
+  for (int round = 0; round < 10 && nlinks; ++round) {  // 2^10 >= the longest chain of links (513)
+    uint32_t kept = 0;
+    for (uint32_t base = 0; base < nlinks; base += CAND_THREADS) {
+      const uint32_t t = base + threadIdx.x;
+      const bool have = t < nlinks;
+      const uint32_t f = have ? links[t] : 0;
+      uint32_t w = have ? res[f] : (1u << 16);
+      const uint32_t tw = res[w & 0x3FF];
+      const bool dead = tw == IDX_INVALID;
+      w = dead ? IDX_INVALID : ((((w >> 16) + (tw >> 16)) << 16) | (tw & 0xFFFF));
+      const bool still = have && !dead && (tw & 0xFFFF) < IDX_DONE;
+      const uint64_t smask = __ballot(still);
+      __syncthreads();  // every lane has read res[] and links[] of this batch (and of the rounds before)
+      if (have) res[f] = w;
+      if (still) links[kept + __popcll(smask & below)] = (uint16_t)f;
+      kept += __popcll(smask);
     }
-    bool any = false;
-#pragma unroll
-    for (int i = 0; i < PER_THREAD; ++i) any = any || link[i];
-    const int pending = __syncthreads_or(any);  // also the barrier between this round's reads and writes
-#pragma unroll
-    for (int i = 0; i < PER_THREAD; ++i)
-      if (link[i]) res[threadIdx.x + i * IDX_THREADS] = w[i];
     __syncthreads();
-    if (!pending) break;  // no links left (typical data resolves in two or three rounds)
+    nlinks = kept;
   }
-  for (uint32_t f = threadIdx.x; f < IDX_CAND; f += IDX_THREADS) {
+  for (uint32_t f = threadIdx.x; f < IDX_CAND; f += CAND_THREADS) {
     const uint32_t w = res[f];
-    table[(size_t)blockIdx.x * IDX_CAND + f] = w == IDX_INVALID ? IDX_INVALID : (w - IDX_DONE);
+    table[(size_t)blockIdx.x * IDX_CAND + f] = (w == IDX_INVALID || (w & 0xFFFF) >= IDX_PENDING) ? w : (w - IDX_DONE);
   }
+}
+
+// Kernel A'.  One lane per slot: the rest of the survivor's walk, from global memory.  slot_result: (records from
+// the slot's first byte on << 16) | bytes into the next chunk, or invalid.
+__global__ __launch_bounds__(64) void k_index_survivors(const uint8_t *stream, size_t nbytes, size_t nslots,
+                                                        const uint32_t *slot_start, uint32_t *slot_result) {
+  const size_t id = (size_t)blockIdx.x * 64 + threadIdx.x;
+  if (id >= nslots) return;
+  const uint32_t start = slot_start[id];
+  if (start == IDX_INVALID) return;  // no reader looks at the result of an empty slot
+  const size_t c0 = id / IDX_SLOTS * IDX_CHUNK;
+  const uint8_t *src = stream + c0;
+  const uint32_t len = (uint32_t)(nbytes - c0 < (size_t)IDX_CHUNK ? nbytes - c0 : (size_t)IDX_CHUNK);
+  uint32_t p = start, cnt = 0;
+  bool bad = false;
+  while (p < len) {
+    const uint32_t bb = src[p];
+    if (bb > 32) {
+      bad = true;
+      break;
+    }
+    p += 1 + 16 * bb;
+    ++cnt;
+  }
+  slot_result[id] = bad ? IDX_INVALID : ((cnt << 16) | (p - len));
+}
+
+// A chunk's table entry with a pending slot resolved.
+__device__ __forceinline__ uint32_t chunk_table_entry(const uint32_t *table, const uint32_t *slot_result, size_t c, uint32_t state) {
+  uint32_t e = table[c * IDX_CAND + state];
+  if (e != IDX_INVALID && (e & 0xFFFF) >= IDX_PENDING) {
+    const uint32_t r = slot_result[c * IDX_SLOTS + (e & 0x7FFF)];
+    e = r == IDX_INVALID ? IDX_INVALID : ((((e >> 16) + (r >> 16)) << 16) | (r & 0xFFFF));
+  }
+  return e;
 }
 
 constexpr int GROUP_THREADS = 576;  // one thread per candidate (513), whole waves
 
-__global__ __launch_bounds__(GROUP_THREADS) void k_index_groups(const uint32_t *table, size_t nchunks, uint64_t *gtable) {
+__global__ __launch_bounds__(GROUP_THREADS) void k_index_groups(const uint32_t *table, const uint32_t *slot_result, size_t nchunks,
+                                                               uint64_t *gtable) {
   if (threadIdx.x >= IDX_CAND) return;
   const size_t cbeg = (size_t)blockIdx.x * IDX_GROUP;
   const size_t cend = cbeg + IDX_GROUP < nchunks ? cbeg + IDX_GROUP : nchunks;
@@ -436,7 +534,7 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_index_groups(const uint32_t *
   uint64_t cnt = 0;
   bool bad = false;
   for (size_t c = cbeg; c < cend; ++c) {
-    const uint32_t e = table[c * IDX_CAND + state];
+    const uint32_t e = chunk_table_entry(table, slot_result, c, state);
     if (e == IDX_INVALID) {
       bad = true;
       break;
@@ -515,7 +613,7 @@ __global__ void k_index_spine(const uint64_t *gtable, size_t ngroups, size_t nby
   result[2] = bad ? 1 : 0;
 }
 
-__global__ __launch_bounds__(64) void k_index_chunk_entries(const uint32_t *table, size_t nchunks, size_t ngroups,
+__global__ __launch_bounds__(64) void k_index_chunk_entries(const uint32_t *table, const uint32_t *slot_result, size_t nchunks, size_t ngroups,
                                                             const uint64_t *gentry, uint64_t *centry) {
   const size_t g = (size_t)blockIdx.x * 64 + threadIdx.x;
   if (g >= ngroups) return;
@@ -530,7 +628,7 @@ __global__ __launch_bounds__(64) void k_index_chunk_entries(const uint32_t *tabl
       continue;
     }
     centry[c] = (base << 16) | state;
-    const uint32_t e = table[c * IDX_CAND + state];
+    const uint32_t e = chunk_table_entry(table, slot_result, c, state);
     if (e == IDX_INVALID) {
       bad = true;  // this chunk still emits the records in front of the bad byte
       continue;
@@ -621,7 +719,7 @@ static size_t idx_supers(size_t ngroups) { return (ngroups + IDX_SUPER - 1) / ID
 size_t stream_index_workspace_bytes(size_t nbytes) {
   const size_t nchunks = idx_chunks(nbytes), ngroups = idx_groups(nchunks), nsupers = idx_supers(ngroups);
   return align256(4 * IDX_CAND * nchunks) + align256(8 * IDX_CAND * ngroups) + align256(8 * IDX_CAND * nsupers) +
-         align256(8 * nsupers) + align256(8 * ngroups) + align256(8 * nchunks) + 256;
+         align256(8 * nsupers) + align256(8 * ngroups) + align256(8 * nchunks) + 2 * align256(4 * IDX_SLOTS * nchunks) + 256;
 }
 
 hipError_t launch_stream_index(const uint8_t *stream, size_t nbytes, size_t max_blocks, uint8_t *bits, uint64_t *off,
@@ -640,14 +738,21 @@ hipError_t launch_stream_index(const uint8_t *stream, size_t nbytes, size_t max_
   uint64_t *gentry = reinterpret_cast<uint64_t *>(ws);
   ws += align256(8 * ngroups);
   uint64_t *centry = reinterpret_cast<uint64_t *>(ws);
-  hipLaunchKernelGGL(k_index_candidates, dim3((unsigned)nchunks), dim3(IDX_THREADS), 0, st, stream, nbytes, table);
-  hipLaunchKernelGGL(k_index_groups, dim3((unsigned)ngroups), dim3(GROUP_THREADS), 0, st, table, nchunks, gtable);
+  ws += align256(8 * nchunks);
+  uint32_t *slot_start = reinterpret_cast<uint32_t *>(ws);
+  ws += align256(4 * IDX_SLOTS * nchunks);
+  uint32_t *slot_result = reinterpret_cast<uint32_t *>(ws);
+  const size_t nslots = nchunks * IDX_SLOTS;
+  hipLaunchKernelGGL(k_index_candidates, dim3((unsigned)nchunks), dim3(CAND_THREADS), 0, st, stream, nbytes, table, slot_start);
+  hipLaunchKernelGGL(k_index_survivors, dim3((unsigned)((nslots + 63) / 64)), dim3(64), 0, st, stream, nbytes, nslots, slot_start,
+                     slot_result);
+  hipLaunchKernelGGL(k_index_groups, dim3((unsigned)ngroups), dim3(GROUP_THREADS), 0, st, table, slot_result, nchunks, gtable);
   hipLaunchKernelGGL(k_index_supers, dim3((unsigned)nsupers), dim3(GROUP_THREADS), 0, st, gtable, ngroups, stable);
   hipLaunchKernelGGL(k_index_spine, dim3(1), dim3(1), 0, st, stable, nsupers, nbytes, sentry, result);
   hipLaunchKernelGGL(k_index_group_entries, dim3((unsigned)((nsupers + 63) / 64)), dim3(64), 0, st, gtable, ngroups, nsupers,
                      sentry, gentry);
-  hipLaunchKernelGGL(k_index_chunk_entries, dim3((unsigned)((ngroups + 63) / 64)), dim3(64), 0, st, table, nchunks, ngroups, gentry,
-                     centry);
+  hipLaunchKernelGGL(k_index_chunk_entries, dim3((unsigned)((ngroups + 63) / 64)), dim3(64), 0, st, table, slot_result, nchunks, ngroups,
+                     gentry, centry);
   hipLaunchKernelGGL(k_index_emit, dim3((unsigned)((nchunks + EMIT_THREADS - 1) / EMIT_THREADS)), dim3(EMIT_THREADS), 0, st, stream,
                      nbytes, centry, nchunks, max_blocks, bits, off);
   return hipGetLastError();

@@ -73,6 +73,7 @@ def stream(n, nblk, reps):
     import numpy as np
 
     dev = torch.device("cuda:0")
+    torch.manual_seed(20260)  # the same stream in every run, so that runs of different builds compare
     w = torch.minimum(torch.randint(0, 21, (nblk,), device=dev), torch.randint(0, 21, (nblk,), device=dev))
     gaps = torch.randint(0, 1 << 30, (n,), dtype=torch.int32, device=dev)
     gaps &= ((1 << w) - 1).to(torch.int32).repeat_interleave(128)
@@ -88,7 +89,8 @@ def stream(n, nblk, reps):
     codec.pack_mixed(1, ids, bits, off, arena, initvalues=seeds)
     strm = codec.stream_build(arena, bits, off, T)
     ibits, ioff, res = codec.stream_index(strm, nblk)
-    assert res.tolist() == [nblk, T, 0] and torch.equal(ibits, bits) and torch.equal(ioff, off)
+    check = not os.environ.get("MB_NOCHECK")  # (timing kernels that were cut down on purpose)
+    assert not check or (res.tolist() == [nblk, T, 0] and torch.equal(ibits, bits) and torch.equal(ioff, off))
     arena2 = codec.stream_unbuild(strm, bits, off, T)
     chained = codec.chain_offsets(strm, bits, off, stream_layout=True)
     assert torch.equal(chained, seeds) and torch.equal(arena2[:T], arena[:T])
@@ -118,11 +120,11 @@ def stream(n, nblk, reps):
     ws_d = torch.empty(max(16, L.simdcomp_hip_stream_decode_workspace(T + nblk, nblk)), dtype=torch.uint8, device=dev)
     for mode, name in ((1, "stream_decode"), (0, "stream_decode_plain")):
         binding.check(L.simdcomp_hip_stream_decode(mode, 0, P(strm), T + nblk, nblk, P(out), P(r3), P(ws_d), st), name)
-        assert r3.tolist() == [nblk, T, 0], r3.tolist()
+        assert not check or r3.tolist() == [nblk, T, 0], r3.tolist()
         if mode == 1:
-            assert torch.equal(out, ids), "stream_decode differs from the input"
+            assert not check or torch.equal(out, ids), "stream_decode differs from the input"
         else:
-            assert torch.equal(out, codec.unpack_stream(0, strm, bits, off, nblk)), "plain stream_decode differs"
+            assert not check or torch.equal(out, codec.unpack_stream(0, strm, bits, off, nblk)), "plain stream_decode differs"
         rows[name] = ((lambda m: lambda: L.simdcomp_hip_stream_decode(m, 0, P(strm), T + nblk, nblk, P(out), P(r3), P(ws_d), st))(mode),
                       512 * nblk + T + nblk)
     res = {"avg_bits": round(T / nblk / 16, 2), "stream_MiB": round((T + nblk) / 2 ** 20, 1)}
