@@ -489,26 +489,54 @@ __global__ __launch_bounds__(CAND_THREADS) void k_index_candidates(const uint8_t
 }
 
 // Kernel A'.  One lane per slot: the rest of the survivor's walk, from global memory.  slot_result: (records from
-// the slot's first byte on << 16) | bytes into the next chunk, or invalid.
+// the slot's first byte on << 16) | bytes into the next chunk, or invalid.  The walk also leaves the width bytes it
+// read in a log (IDX_LOG records; a slot takes its log from a pool with a wave-wide atomic), so that the kernel that
+// writes the index does not walk the true chain a second time.
+constexpr uint32_t IDX_LOG = 1024;  // a 16 KiB chunk holds at most 964 records of one bit or more
+
+static size_t idx_log_regions(size_t nchunks) { return nchunks + nchunks / 2 + 64; }
+
 __global__ __launch_bounds__(64) void k_index_survivors(const uint8_t *stream, size_t nbytes, size_t nslots,
-                                                        const uint32_t *slot_start, uint32_t *slot_result) {
+                                                        const uint32_t *slot_start, uint32_t *slot_result, uint32_t *slot_log,
+                                                        uint32_t *pool_next, uint32_t nregions, uint8_t *logs) {
   const size_t id = (size_t)blockIdx.x * 64 + threadIdx.x;
-  if (id >= nslots) return;
-  const uint32_t start = slot_start[id];
-  if (start == IDX_INVALID) return;  // no reader looks at the result of an empty slot
+  const uint32_t start = id < nslots ? slot_start[id] : IDX_INVALID;
+  const bool have = start != IDX_INVALID;
+  const uint64_t mask = __ballot(have);
+  if (mask == 0) return;
+  uint32_t first = 0;
+  if (threadIdx.x == (uint32_t)(__ffsll((unsigned long long)mask) - 1)) first = atomicAdd(pool_next, (uint32_t)__popcll(mask));
+  first = __shfl(first, __ffsll((unsigned long long)mask) - 1);
+  if (!have) return;  // no reader looks at the result of an empty slot
+  uint32_t region = first + (uint32_t)__popcll(mask & ((1ull << threadIdx.x) - 1));
+  if (region >= nregions) region = IDX_INVALID;  // (streams made to have many survivors: the index is written by a walk)
+  slot_log[id] = region;
   const size_t c0 = id / IDX_SLOTS * IDX_CHUNK;
   const uint8_t *src = stream + c0;
   const uint32_t len = (uint32_t)(nbytes - c0 < (size_t)IDX_CHUNK ? nbytes - c0 : (size_t)IDX_CHUNK);
   uint32_t p = start, cnt = 0;
   bool bad = false;
-  while (p < len) {
-    const uint32_t bb = src[p];
-    if (bb > 32) {
-      bad = true;
-      break;
+  typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+  u64x2 *log = reinterpret_cast<u64x2 *>(logs + (size_t)region * IDX_LOG);
+  while (p < len && !bad) {
+    // sixteen dependent loads, then one store (memory operations of a wave complete in order: a load issued
+    // behind a store waits for it as well)
+    uint64_t packed[2] = {0, 0};
+    const uint32_t at = cnt;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      if (p < len && !bad) {
+        const uint32_t bb = src[p];
+        if (bb > 32) {
+          bad = true;
+        } else {
+          packed[i / 8] |= (uint64_t)bb << (8 * (i % 8));
+          p += 1 + 16 * bb;
+          ++cnt;
+        }
+      }
     }
-    p += 1 + 16 * bb;
-    ++cnt;
+    if (region != IDX_INVALID && at + 16 <= IDX_LOG) log[at / 16] = u64x2{packed[0], packed[1]};
   }
   slot_result[id] = bad ? IDX_INVALID : ((cnt << 16) | (p - len));
 }
@@ -639,69 +667,96 @@ __global__ __launch_bounds__(64) void k_index_chunk_entries(const uint32_t *tabl
 }
 
 constexpr int EMIT_THREADS = 64;
+constexpr int EMIT_LANES = 16;  // lanes per chunk: one DPP row
 
-// Kernel E: one lane per chunk follows the chunk's true chain straight from global memory and writes width and
-// offset of every record it passes.  A step costs a global round trip instead of an LDS one, but nothing is staged,
-// so every chunk of the stream is walked at the same time (staging each chunk in LDS for one walking lane kept only
-// 8 chunks per CU in flight and measured 3x slower).
+// Kernel E: sixteen lanes per chunk write width and offset of every record of the chunk's true chain.  The chain is
+// followed from global memory (all sixteen lanes read the same byte) until it arrives at the first byte of one of the
+// chunk's slots; from there on the widths are in the slot's log, sixteen records per step: offsets by a prefix sum
+// over the row.  A slot without a log, a log that is too short or a chain with a bad byte are walked to the end.
 __global__ __launch_bounds__(EMIT_THREADS) void k_index_emit(const uint8_t *stream, size_t nbytes, const uint64_t *centry,
-                                                             size_t nchunks, size_t max_blocks, uint8_t *bits, uint64_t *off) {
-  const size_t c = (size_t)blockIdx.x * EMIT_THREADS + threadIdx.x;
-  if (c >= nchunks) return;
-  const uint64_t ce = centry[c];
-  if (ce == IDX_INVALID64) return;
+                                                             size_t nchunks, size_t max_blocks, const uint32_t *slot_start,
+                                                             const uint32_t *slot_result, const uint32_t *slot_log,
+                                                             const uint8_t *logs, uint8_t *bits, uint64_t *off) {
+  const size_t c = ((size_t)blockIdx.x * EMIT_THREADS + threadIdx.x) / EMIT_LANES;
+  const uint32_t sub = threadIdx.x % EMIT_LANES;
+  const uint64_t ce = c < nchunks ? centry[c] : IDX_INVALID64;
+  bool ok = ce != IDX_INVALID64;
   const size_t c0 = c * IDX_CHUNK;
-  const size_t end = c0 + IDX_CHUNK < nbytes ? c0 + IDX_CHUNK : nbytes;
-  size_t p = c0 + (ce & 0xFFFF);
+  const uint8_t *src = stream + c0;
+  const uint32_t len = !ok ? 0 : (uint32_t)(nbytes - c0 < (size_t)IDX_CHUNK ? nbytes - c0 : (size_t)IDX_CHUNK);
+  uint32_t p = (uint32_t)(ce & 0xFFFF);
   uint64_t r = ce >> 16;
-  // Memory operations of a wave complete in order, so a width byte requested behind the stores of the previous
-  // record would wait for them as well: eight records are walked first (eight dependent loads), then written.
-  constexpr int BATCH = 8;  // (the packed width bytes below fill one 64-bit word)
-  bool ok = true;
-  while (ok && p < end) {
-    size_t ps[BATCH];
-    uint32_t bs[BATCH];
-    int n = 0;
+  uint32_t starts[IDX_SLOTS];
 #pragma unroll
-    for (int i = 0; i < BATCH; ++i) {
-      if (ok && p < end) {
-        const uint32_t b = stream[p];
-        if (b > 32 || p + 1 + 16 * (size_t)b > nbytes) {
-          // a bad width byte, or a record that runs past the end of the stream: the spine has already reported the
-          // stream as bad; nothing is written for it, so that no later kernel reads a payload beyond the stream
-          ok = false;
-        } else {
-          ps[i] = p;
-          bs[i] = b;
-          p += 1 + 16 * (size_t)b;
-          n = i + 1;
+  for (int k = 0; k < IDX_SLOTS; ++k) starts[k] = ok ? slot_start[c * IDX_SLOTS + k] : IDX_INVALID;
+  // (every lane of the row takes the same path through this function)  Records are handed to the lanes of the row
+  // in turn and written sixteen at a time, so that the loads of the walk do not queue behind single stores.
+  uint32_t held = 0, my_b = 0;
+  size_t my_at = 0;
+  auto flush = [&]() {
+    if (sub < held && r - held + sub < max_blocks) {
+      bits[r - held + sub] = (uint8_t)my_b;
+      off[r - held + sub] = my_at - (r - held + sub);
+    }
+    held = 0;
+  };
+  auto walk = [&](bool to_slot) -> int {
+    while (ok && p < len) {
+      if (to_slot) {
+#pragma unroll
+        for (int k = 0; k < IDX_SLOTS; ++k)
+          if (starts[k] == p) return k;
+      }
+      const uint32_t b = src[p];
+      if (b > 32 || c0 + p + 1 + 16 * (size_t)b > nbytes) {
+        // a bad width byte, or a record that runs past the end of the stream: the spine has already reported the
+        // stream as bad; nothing is written for it, so that no later kernel reads a payload beyond the stream
+        ok = false;
+      } else {
+        if (sub == held) {
+          my_b = b;
+          my_at = c0 + p;
         }
+        p += 1 + 16 * b;
+        ++r;
+        if (++held == EMIT_LANES) flush();
       }
     }
-    if (n == BATCH && r + BATCH <= max_blocks) {
-      // a full batch leaves as four 16-byte stores and one 8-byte store (at whatever alignment r gives them)
-      // instead of sixteen single stores
-      typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
-      typedef u64x2 u64x2_u __attribute__((aligned(1)));
-      typedef uint64_t u64_u __attribute__((aligned(1)));
-      uint64_t packed = 0;
-#pragma unroll
-      for (int i = 0; i < BATCH; ++i) packed |= (uint64_t)bs[i] << (8 * i);
-      *reinterpret_cast<u64_u *>(bits + r) = packed;
-#pragma unroll
-      for (int i = 0; i < BATCH; i += 2)
-        *reinterpret_cast<u64x2_u *>(off + r + i) = u64x2{ps[i] - (r + i), ps[i + 1] - (r + i + 1)};
-    } else {
-#pragma unroll
-      for (int i = 0; i < BATCH; ++i) {
-        if (i < n && r + i < max_blocks) {
-          bits[r + i] = (uint8_t)bs[i];
-          off[r + i] = ps[i] - (r + i);
-        }
-      }
+    return -1;
+  };
+  const int slot = walk(true);
+  flush();
+  uint32_t logged = 0, records = 0;
+  const uint8_t *log = logs;
+  if (slot >= 0) {
+    const uint32_t res = slot_result[c * IDX_SLOTS + slot], region = slot_log[c * IDX_SLOTS + slot];
+    if (res != IDX_INVALID && region != IDX_INVALID) {
+      records = res >> 16;
+      logged = records < IDX_LOG ? records : IDX_LOG;
+      log = logs + (size_t)region * IDX_LOG;
     }
-    r += n;
   }
+  for (uint32_t i0 = 0; __any(i0 < logged); i0 += EMIT_LANES) {  // (the rows of a wave stay in step for the DPP scan)
+    const uint32_t i = i0 + sub;
+    const bool have = i < logged;
+    const uint32_t b = have ? log[i] : 0;
+    const uint32_t size = have ? 1 + 16 * b : 0;
+    uint32_t incl = size;
+    incl += dpp0<DPP_ROW_SHR1>(incl);
+    incl += dpp0<DPP_ROW_SHR2>(incl);
+    incl += dpp0<DPP_ROW_SHR4>(incl);
+    incl += dpp0<DPP_ROW_SHR8>(incl);
+    const size_t at = c0 + p + incl - size;
+    if (have && at + size <= nbytes && r + i0 + sub < max_blocks) {
+      bits[r + i] = (uint8_t)b;
+      off[r + i] = at - (r + i);
+    }
+    p += __shfl(incl, (int)((threadIdx.x & ~(EMIT_LANES - 1)) + EMIT_LANES - 1));
+  }
+  r += logged;
+  if (slot >= 0 && logged == records && records != 0) return;  // the log held the rest of the chunk
+  walk(false);
+  flush();
 }
 
 __global__ void k_stream_bytes(const uint64_t *payload_bytes, uint64_t nblocks, uint64_t *out) { *out = *payload_bytes + nblocks; }
@@ -719,7 +774,8 @@ static size_t idx_supers(size_t ngroups) { return (ngroups + IDX_SUPER - 1) / ID
 size_t stream_index_workspace_bytes(size_t nbytes) {
   const size_t nchunks = idx_chunks(nbytes), ngroups = idx_groups(nchunks), nsupers = idx_supers(ngroups);
   return align256(4 * IDX_CAND * nchunks) + align256(8 * IDX_CAND * ngroups) + align256(8 * IDX_CAND * nsupers) +
-         align256(8 * nsupers) + align256(8 * ngroups) + align256(8 * nchunks) + 2 * align256(4 * IDX_SLOTS * nchunks) + 256;
+         align256(8 * nsupers) + align256(8 * ngroups) + align256(8 * nchunks) + 3 * align256(4 * IDX_SLOTS * nchunks) + 256 +
+         align256(idx_log_regions(nchunks) * IDX_LOG) + 256;
 }
 
 hipError_t launch_stream_index(const uint8_t *stream, size_t nbytes, size_t max_blocks, uint8_t *bits, uint64_t *off,
@@ -742,10 +798,19 @@ hipError_t launch_stream_index(const uint8_t *stream, size_t nbytes, size_t max_
   uint32_t *slot_start = reinterpret_cast<uint32_t *>(ws);
   ws += align256(4 * IDX_SLOTS * nchunks);
   uint32_t *slot_result = reinterpret_cast<uint32_t *>(ws);
-  const size_t nslots = nchunks * IDX_SLOTS;
+  ws += align256(4 * IDX_SLOTS * nchunks);
+  uint32_t *slot_log = reinterpret_cast<uint32_t *>(ws);
+  ws += align256(4 * IDX_SLOTS * nchunks);
+  uint32_t *pool_next = reinterpret_cast<uint32_t *>(ws);
+  ws += 256;
+  uint8_t *logs = ws;
+  const size_t nslots = nchunks * IDX_SLOTS, nregions = idx_log_regions(nchunks);
+  if (nregions > 0xFFFFFFF0ull) return hipErrorInvalidValue;  // (a stream of more than 40 TiB)
+  hipError_t e = hipMemsetAsync(pool_next, 0, sizeof(uint32_t), st);
+  if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_index_candidates, dim3((unsigned)nchunks), dim3(CAND_THREADS), 0, st, stream, nbytes, table, slot_start);
   hipLaunchKernelGGL(k_index_survivors, dim3((unsigned)((nslots + 63) / 64)), dim3(64), 0, st, stream, nbytes, nslots, slot_start,
-                     slot_result);
+                     slot_result, slot_log, pool_next, (uint32_t)nregions, logs);
   hipLaunchKernelGGL(k_index_groups, dim3((unsigned)ngroups), dim3(GROUP_THREADS), 0, st, table, slot_result, nchunks, gtable);
   hipLaunchKernelGGL(k_index_supers, dim3((unsigned)nsupers), dim3(GROUP_THREADS), 0, st, gtable, ngroups, stable);
   hipLaunchKernelGGL(k_index_spine, dim3(1), dim3(1), 0, st, stable, nsupers, nbytes, sentry, result);
@@ -753,8 +818,9 @@ hipError_t launch_stream_index(const uint8_t *stream, size_t nbytes, size_t max_
                      sentry, gentry);
   hipLaunchKernelGGL(k_index_chunk_entries, dim3((unsigned)((ngroups + 63) / 64)), dim3(64), 0, st, table, slot_result, nchunks, ngroups,
                      gentry, centry);
-  hipLaunchKernelGGL(k_index_emit, dim3((unsigned)((nchunks + EMIT_THREADS - 1) / EMIT_THREADS)), dim3(EMIT_THREADS), 0, st, stream,
-                     nbytes, centry, nchunks, max_blocks, bits, off);
+  constexpr size_t per_wg = EMIT_THREADS / EMIT_LANES;
+  hipLaunchKernelGGL(k_index_emit, dim3((unsigned)((nchunks + per_wg - 1) / per_wg)), dim3(EMIT_THREADS), 0, st, stream, nbytes, centry,
+                     nchunks, max_blocks, slot_start, slot_result, slot_log, logs, bits, off);
   return hipGetLastError();
 }
 
