@@ -299,15 +299,20 @@ hipError_t launch_stream_unbuild(const uint8_t *stream, const uint64_t *off, con
 // ---------------------------------------------------------------------------
 // Record k+1 starts 1 + 16*b_k bytes after record k: a chain through the data.  It is cut into chunks of IDX_CHUNK
 // bytes.  The first record of a chunk starts at one of 513 places (a record is at most 513 bytes long), so
-//   A  every chunk walks the chain from all 513 candidate entries at once (chunk staged in LDS) and tabulates, per
-//      candidate, where the walk leaves the chunk (0..512 bytes into the next one) and how many records it saw;
+//   A  every chunk tabulates, per candidate, where the walk from it leaves the chunk (0..512 bytes into the next
+//      one) and how many records it sees: the candidates are resolved against each other inside the first 1.5 KiB of
+//      the chunk (kernel A, that part staged in LDS), the few walks that are still alive behind it are finished from
+//      global memory, every chunk of the stream at the same time (kernel A'), logging the widths they read;
 //   B  groups of IDX_GROUP chunks compose their tables (thread f follows candidate f through the group), and
 //      super-groups of IDX_SUPER groups compose the group tables the same way: a chain of 32 dependent loads each,
 //      instead of one long chain;
 //   C  one thread walks the super-group tables from the known entry of the stream (byte 0) and fixes every
 //      super-group's entry and first record number;  D  one thread per super-group does the same for its groups,
 //      then one thread per group for its chunks;
-//   E  every chunk walks its true chain once more and writes width and arena offset of each record.
+//   E  every chunk writes width and arena offset of each record of its true chain: the few records in front of the
+//      logged walk by walking, the rest from the log.
+// (Staging whole chunks in LDS for A and walking the true chain again in E, as this code did at first, cost 0.58 ms
+// and 0.22 ms per GiB of stream; A + A' take 0.14 + 0.27 ms, E 0.06 ms.)
 // A width byte above 32 ends a walk as invalid; the true chain hitting one is reported in result[2].
 #ifndef SC_IDX_CHUNK
 #define SC_IDX_CHUNK 16384
@@ -336,7 +341,7 @@ constexpr uint32_t IDX_PENDING = 0x8000;
 #define SC_IDX_SLOTS 4
 #endif
 #ifndef SC_IDX_PROBE
-#define SC_IDX_PROBE 4
+#define SC_IDX_PROBE 3
 #endif
 constexpr int IDX_SLOTS = SC_IDX_SLOTS;
 constexpr int IDX_PROBE = SC_IDX_PROBE;
@@ -346,59 +351,102 @@ __global__ __launch_bounds__(CAND_THREADS) void k_index_candidates(const uint8_t
                                                                    uint32_t *slot_start) {
   constexpr uint32_t BOUNDARY = IDX_CAND * IDX_PROBE;  // roots walk until they cross this byte
   constexpr uint32_t WINDOW = BOUNDARY;                // so this much of the chunk is staged
+  // (the workgroup is one wave: a wave-level fence is all the synchronisation the LDS arrays need.  The kernel is
+  // bound by instruction issue, about a thousand instructions per chunk; several chunks per workgroup, one per
+  // wave, measured the same.)
   __shared__ u32x4 window[(WINDOW + 15) / 16];
   __shared__ uint32_t res[IDX_CAND];
-  __shared__ uint16_t roots[IDX_CAND];
-  __shared__ uint16_t links[IDX_CAND];
-  const size_t c0 = (size_t)blockIdx.x * IDX_CHUNK;
+  __shared__ uint16_t lists[IDX_CAND + 1];  // roots from the front, links from the back (a candidate is one or neither)
+  const uint32_t lane = threadIdx.x;
+  const size_t chunk = blockIdx.x;
+  const size_t c0 = chunk * IDX_CHUNK;
   const uint8_t *src = stream + c0;
   const uint32_t len = (uint32_t)(nbytes - c0 < (size_t)IDX_CHUNK ? nbytes - c0 : (size_t)IDX_CHUNK);
   const uint32_t win = len < WINDOW ? len : WINDOW;
   uint8_t *by = reinterpret_cast<uint8_t *>(window);
-  for (uint32_t i = threadIdx.x; 16 * (i + 1) <= win; i += CAND_THREADS) window[i] = *reinterpret_cast<const u32x4_u *>(src + 16 * i);
-  for (uint32_t j = (win & ~15u) + threadIdx.x; j < win; j += CAND_THREADS) by[j] = src[j];
-  __syncthreads();
-  // the workgroup is one wave: roots and links are gathered into lists with ballots (counts the same in every lane)
-  const uint64_t below = (1ull << threadIdx.x) - 1;
-  uint32_t total = 0, nlinks = 0;
-  for (uint32_t f = threadIdx.x; f < IDX_CAND + CAND_THREADS - 1; f += CAND_THREADS) {
-    uint32_t word = IDX_INVALID;
-    bool root = false, link = false;
+  {
+    // all loads of the lane first, then the LDS writes (one global round trip, not one per 1 KiB)
+    constexpr int VECS = ((WINDOW + 15) / 16 + CAND_THREADS - 1) / CAND_THREADS;
+    u32x4 v[VECS];
+    uint8_t tail = 0;
+    const uint32_t j = (win & ~15u) + lane;  // (at most 15 bytes behind the last whole vector)
+#pragma unroll
+    for (int k = 0; k < VECS; ++k) {
+      const uint32_t i = lane + k * CAND_THREADS;
+      if (16 * (i + 1) <= win) v[k] = *reinterpret_cast<const u32x4_u *>(src + 16 * i);
+    }
+    if (j < win) tail = src[j];
+#pragma unroll
+    for (int k = 0; k < VECS; ++k) {
+      const uint32_t i = lane + k * CAND_THREADS;
+      if (16 * (i + 1) <= win) window[i] = v[k];
+    }
+    if (j < win) by[j] = tail;
+  }
+  wave_lds_fence();
+  // every lane counts the roots and links among its own candidates, one prefix sum over the wave gives it its
+  // places in the two lists (both counts in one word)
+  constexpr int PER_LANE = (IDX_CAND + CAND_THREADS - 1) / CAND_THREADS;
+  uint32_t width[PER_LANE];
+#pragma unroll
+  for (int k = 0; k < PER_LANE; ++k) {
+    const uint32_t f = lane + k * CAND_THREADS;
+    width[k] = f < IDX_CAND && f < len ? by[f] : 0xFF;
+  }
+  uint32_t rootbits = 0, linkbits = 0;
+#pragma unroll
+  for (int k = 0; k < PER_LANE; ++k) {
+    const uint32_t f = lane + k * CAND_THREADS;
     if (f < IDX_CAND) {
+      uint32_t word = IDX_INVALID;
       if (f >= len) {
         word = IDX_DONE + (f - len);  // the chunk is shorter than the candidate window
       } else {
-        const uint32_t b = by[f];
+        const uint32_t b = width[k];
         const uint32_t nf = f + 1 + 16 * b;
         if (b > 32) {
         } else if (nf >= len) {
           word = (1u << 16) | (IDX_DONE + nf - len);
         } else if (nf < IDX_CAND) {
           word = (1u << 16) | nf;
-          link = true;
+          linkbits |= 1u << k;
         } else {
-          root = true;  // res[f] comes from the walk below
+          rootbits |= 1u << k;  // res[f] comes from the walk below
         }
       }
       res[f] = word;
     }
-    const uint64_t rmask = __ballot(root), lmask = __ballot(link);
-    if (root) roots[total + __popcll(rmask & below)] = (uint16_t)f;
-    if (link) links[nlinks + __popcll(lmask & below)] = (uint16_t)f;
-    total += __popcll(rmask);
-    nlinks += __popcll(lmask);
   }
-  __syncthreads();
+  const uint32_t mine = (uint32_t)__popc(rootbits) | ((uint32_t)__popc(linkbits) << 16);
+  uint32_t incl = mine;
+  incl += dpp0<DPP_ROW_SHR1>(incl);
+  incl += dpp0<DPP_ROW_SHR2>(incl);
+  incl += dpp0<DPP_ROW_SHR4>(incl);
+  incl += dpp0<DPP_ROW_SHR8>(incl);
+  incl += dpp0<DPP_ROW_BCAST15, 0xA>(incl);
+  incl += dpp0<DPP_ROW_BCAST31, 0xC>(incl);
+  const uint32_t all = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+  const uint32_t total = all & 0xFFFF;
+  uint32_t nlinks = all >> 16;
+  uint32_t root_at = (incl - mine) & 0xFFFF, link_at = (incl - mine) >> 16;
+  while (rootbits) {
+    const int k = __ffs((int)rootbits) - 1;
+    rootbits &= rootbits - 1;
+    lists[root_at++] = (uint16_t)(lane + k * CAND_THREADS);
+  }
+  while (linkbits) {
+    const int k = __ffs((int)linkbits) - 1;
+    linkbits &= linkbits - 1;
+    lists[IDX_CAND - link_at++] = (uint16_t)(lane + k * CAND_THREADS);
+  }
+  wave_lds_fence();
   uint32_t slot_pos[IDX_SLOTS];
   uint32_t nslots = 0;  // both the same in every lane
 #pragma unroll
   for (int k = 0; k < IDX_SLOTS; ++k) slot_pos[k] = IDX_INVALID;
-#ifdef SC_DBG_NOROOTS
-  total = 0;
-#endif
   for (uint32_t base = 0; base < total; base += CAND_THREADS) {
-    const uint32_t t = base + threadIdx.x;
-    const uint32_t r = t < total ? roots[t] : 0;
+    const uint32_t t = base + lane;
+    const uint32_t r = t < total ? lists[t] : 0;
     uint32_t p = r + 1 + 16 * (uint32_t)by[r], cnt = 1;
     bool walking = t < total, dead = false;
     while (walking && p < BOUNDARY) {
@@ -432,7 +480,6 @@ __global__ __launch_bounds__(CAND_THREADS) void k_index_candidates(const uint8_t
       if (same) slot = s;
       todo &= ~__ballot(same);
     }
-#ifndef SC_DBG_NOWALK
     if (walking && slot < 0) {
       // more distinct survivors than slots (streams made to look like that): this one walks to the end right here
       while (p < len) {
@@ -446,45 +493,50 @@ __global__ __launch_bounds__(CAND_THREADS) void k_index_candidates(const uint8_t
       }
       walking = false;
     }
-#endif
     if (t < total)
       res[r] = dead ? IDX_INVALID : ((cnt << 16) | (walking ? IDX_PENDING + (uint32_t)slot : IDX_DONE + p - len));
   }
-  if (threadIdx.x < IDX_SLOTS) {
+  if (lane < IDX_SLOTS) {
     uint32_t v = IDX_INVALID;
 #pragma unroll
     for (int k = 0; k < IDX_SLOTS; ++k)
-      if ((int)threadIdx.x == k) v = slot_pos[k];
-    slot_start[(size_t)blockIdx.x * IDX_SLOTS + threadIdx.x] = v;
+      if ((int)lane == k) v = slot_pos[k];
+    slot_start[chunk * IDX_SLOTS + lane] = v;
   }
-  __syncthreads();
+  wave_lds_fence();
+  const uint64_t below = (1ull << lane) - 1;
   // pointer jumping over the links only; a link whose target is resolved is resolved itself and leaves the list
-#ifdef SC_DBG_NOPJ
-  nlinks = 0;
-#endif
   for (int round = 0; round < 10 && nlinks; ++round) {  // 2^10 >= the longest chain of links (513)
     uint32_t kept = 0;
     for (uint32_t base = 0; base < nlinks; base += CAND_THREADS) {
-      const uint32_t t = base + threadIdx.x;
+      const uint32_t t = base + lane;
       const bool have = t < nlinks;
-      const uint32_t f = have ? links[t] : 0;
+      const uint32_t f = have ? lists[IDX_CAND - t] : 0;
       uint32_t w = have ? res[f] : (1u << 16);
       const uint32_t tw = res[w & 0x3FF];
       const bool dead = tw == IDX_INVALID;
       w = dead ? IDX_INVALID : ((((w >> 16) + (tw >> 16)) << 16) | (tw & 0xFFFF));
       const bool still = have && !dead && (tw & 0xFFFF) < IDX_DONE;
       const uint64_t smask = __ballot(still);
-      __syncthreads();  // every lane has read res[] and links[] of this batch (and of the rounds before)
+      wave_lds_fence();  // every lane has read res[] and links[] of this batch (and of the rounds before)
       if (have) res[f] = w;
-      if (still) links[kept + __popcll(smask & below)] = (uint16_t)f;
+      if (still) lists[IDX_CAND - (kept + __popcll(smask & below))] = (uint16_t)f;
       kept += __popcll(smask);
     }
-    __syncthreads();
+    wave_lds_fence();
     nlinks = kept;
   }
-  for (uint32_t f = threadIdx.x; f < IDX_CAND; f += CAND_THREADS) {
-    const uint32_t w = res[f];
-    table[(size_t)blockIdx.x * IDX_CAND + f] = (w == IDX_INVALID || (w & 0xFFFF) >= IDX_PENDING) ? w : (w - IDX_DONE);
+  uint32_t out[PER_LANE];
+#pragma unroll
+  for (int k = 0; k < PER_LANE; ++k) {
+    const uint32_t f = lane + k * CAND_THREADS;
+    out[k] = f < IDX_CAND ? res[f] : IDX_INVALID;
+  }
+#pragma unroll
+  for (int k = 0; k < PER_LANE; ++k) {
+    const uint32_t f = lane + k * CAND_THREADS, w = out[k];
+    if (f < IDX_CAND)
+      table[chunk * IDX_CAND + f] = (w == IDX_INVALID || (w & 0xFFFF) >= IDX_PENDING) ? w : (w - IDX_DONE);
   }
 }
 

@@ -333,6 +333,32 @@ def decode_call(d1, d, nblk, init=0):
     return u32(out[: nblk * 128]), res.tolist()
 
 
+@pytest.mark.parametrize("width", [1, 2, 5])
+def test_index_every_byte_starts_a_chain(dev, orc, width):
+    """A stream of one repeated byte value v (records of 1 + 16 v bytes whose payload bytes all equal v): a walk from
+    ANY byte is valid and never meets the true chain, so every index chunk has 1 + 16 v live chains that differ only in
+    phase -- more than the index keeps slots or logs for.  The index has to come out right all the same, and the
+    decode equals the CPU loop."""
+    import torch
+
+    nblk = 3 * (1 << 20) // (1 + 16 * width)  # about 3 MiB: some 190 index chunks
+    nbytes = nblk * (1 + 16 * width)
+    stream = np.full(nbytes, width, np.uint8)
+    bits, off, res = dev.stream_index(to_dev(stream), nblk)
+    assert res.tolist() == [nblk, nbytes - nblk, 0]
+    assert (bits == width).all()
+    assert np.array_equal(off.cpu().numpy(), np.arange(nblk, dtype=np.int64) * 16 * width)
+    # one byte short: the last record does not fit, everything in front of it is indexed and the stream reported bad
+    bits, off, res = dev.stream_index(to_dev(stream[:-1]), nblk)
+    assert res.tolist()[2] == 1
+    assert (bits[: nblk - 1] == width).all()
+    assert np.array_equal(off.cpu().numpy()[: nblk - 1], np.arange(nblk - 1, dtype=np.int64) * 16 * width)
+    few = 4000
+    out, res = decode_call(True, to_dev(stream[: few * (1 + 16 * width)]), few, init=7)
+    assert res == [few, few * 16 * width, 0]
+    assert np.array_equal(out, orc.stream_decode(stream[: few * (1 + 16 * width)], few, d1=True, initvalue=7))
+
+
 @pytest.mark.parametrize("seed", [4, 5])
 def test_decode_adversarial_payloads(dev, orc, seed):
     """The one-call decode over streams whose payload bytes look like width bytes (false chains everywhere, several
