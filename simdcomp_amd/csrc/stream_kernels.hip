@@ -338,7 +338,7 @@ constexpr uint64_t IDX_INVALID64 = ~0ull;
 constexpr uint32_t IDX_DONE = 1024;
 constexpr uint32_t IDX_PENDING = 0x8000;
 #ifndef SC_IDX_SLOTS
-#define SC_IDX_SLOTS 4
+#define SC_IDX_SLOTS 8
 #endif
 #ifndef SC_IDX_PROBE
 #define SC_IDX_PROBE 3
@@ -548,19 +548,43 @@ constexpr uint32_t IDX_LOG = 1024;  // a 16 KiB chunk holds at most 964 records 
 
 static size_t idx_log_regions(size_t nchunks) { return nchunks + nchunks / 2 + 64; }
 
-__global__ __launch_bounds__(64) void k_index_survivors(const uint8_t *stream, size_t nbytes, size_t nslots,
-                                                        const uint32_t *slot_start, uint32_t *slot_result, uint32_t *slot_log,
-                                                        uint32_t *pool_next, uint32_t nregions, uint8_t *logs) {
-  const size_t id = (size_t)blockIdx.x * 64 + threadIdx.x;
-  const uint32_t start = id < nslots ? slot_start[id] : IDX_INVALID;
-  const bool have = start != IDX_INVALID;
-  const uint64_t mask = __ballot(have);
-  if (mask == 0) return;
+constexpr int SURV_THREADS = 1024;
+
+__global__ __launch_bounds__(SURV_THREADS) void k_index_survivors(const uint8_t *stream, size_t nbytes, size_t nslots,
+                                                                  const uint32_t *slot_start, uint32_t *slot_result,
+                                                                  uint32_t *slot_log, uint32_t *pool_next, uint32_t nregions,
+                                                                  uint8_t *logs) {
+  // Most slots are empty (a chunk has IDX_SLOTS of them and typically uses one): the workgroup looks at 1024 slots,
+  // gathers the live ones into its first lanes and lets the other waves go, so that the walk below runs in full
+  // waves (with the live slots scattered over all waves, at a quarter of the lanes, it ran 15 % slower, and slower
+  // still with more slots per chunk).
+  __shared__ uint16_t live[SURV_THREADS];
+  __shared__ uint32_t wave_count[SURV_THREADS / 64];
+  const uint32_t wave = threadIdx.x / 64, lane = threadIdx.x % 64;
+  const size_t first_id = (size_t)blockIdx.x * SURV_THREADS;
+  {
+    const size_t id = first_id + threadIdx.x;
+    const bool have = id < nslots && slot_start[id] != IDX_INVALID;
+    const uint64_t mask = __ballot(have);
+    if (lane == 0) wave_count[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    uint32_t before = 0;
+    for (uint32_t w = 0; w < wave; ++w) before += wave_count[w];
+    if (have) live[before + (uint32_t)__popcll(mask & ((1ull << lane) - 1))] = (uint16_t)threadIdx.x;
+    __syncthreads();
+  }
+  uint32_t nlive = 0;
+#pragma unroll
+  for (int w = 0; w < SURV_THREADS / 64; ++w) nlive += wave_count[w];
+  if (threadIdx.x >= nlive) return;  // (whole waves leave here, and the tail of the last live one)
+  const size_t id = first_id + live[threadIdx.x];
+  const uint32_t start = slot_start[id];
+  // a log for every lane that is left: one atomic per wave
+  const uint32_t mine = nlive - wave * 64 < 64 ? nlive - wave * 64 : 64;
   uint32_t first = 0;
-  if (threadIdx.x == (uint32_t)(__ffsll((unsigned long long)mask) - 1)) first = atomicAdd(pool_next, (uint32_t)__popcll(mask));
-  first = __shfl(first, __ffsll((unsigned long long)mask) - 1);
-  if (!have) return;  // no reader looks at the result of an empty slot
-  uint32_t region = first + (uint32_t)__popcll(mask & ((1ull << threadIdx.x) - 1));
+  if (lane == 0) first = atomicAdd(pool_next, mine);
+  first = __shfl(first, 0);
+  uint32_t region = first + lane;
   if (region >= nregions) region = IDX_INVALID;  // (streams made to have many survivors: the index is written by a walk)
   slot_log[id] = region;
   const size_t c0 = id / IDX_SLOTS * IDX_CHUNK;
@@ -578,7 +602,7 @@ __global__ __launch_bounds__(64) void k_index_survivors(const uint8_t *stream, s
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       if (p < len && !bad) {
-        const uint32_t bb = src[p];
+        const uint32_t bb = src[p];  // (a non-temporal load here: 9 % slower)
         if (bb > 32) {
           bad = true;
         } else {
@@ -861,8 +885,8 @@ hipError_t launch_stream_index(const uint8_t *stream, size_t nbytes, size_t max_
   hipError_t e = hipMemsetAsync(pool_next, 0, sizeof(uint32_t), st);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_index_candidates, dim3((unsigned)nchunks), dim3(CAND_THREADS), 0, st, stream, nbytes, table, slot_start);
-  hipLaunchKernelGGL(k_index_survivors, dim3((unsigned)((nslots + 63) / 64)), dim3(64), 0, st, stream, nbytes, nslots, slot_start,
-                     slot_result, slot_log, pool_next, (uint32_t)nregions, logs);
+  hipLaunchKernelGGL(k_index_survivors, dim3((unsigned)((nslots + SURV_THREADS - 1) / SURV_THREADS)), dim3(SURV_THREADS), 0, st,
+                     stream, nbytes, nslots, slot_start, slot_result, slot_log, pool_next, (uint32_t)nregions, logs);
   hipLaunchKernelGGL(k_index_groups, dim3((unsigned)ngroups), dim3(GROUP_THREADS), 0, st, table, slot_result, nchunks, gtable);
   hipLaunchKernelGGL(k_index_supers, dim3((unsigned)nsupers), dim3(GROUP_THREADS), 0, st, gtable, ngroups, stable);
   hipLaunchKernelGGL(k_index_spine, dim3(1), dim3(1), 0, st, stable, nsupers, nbytes, sentry, result);
