@@ -631,14 +631,23 @@ constexpr int GROUP_THREADS = 576;  // one thread per candidate (513), whole wav
 
 __global__ __launch_bounds__(GROUP_THREADS) void k_index_groups(const uint32_t *table, const uint32_t *slot_result, size_t nchunks,
                                                                uint64_t *gtable) {
-  if (threadIdx.x >= IDX_CAND) return;
+  // the slot results of the group's chunks go to LDS first: the second of the two dependent loads per chunk then
+  // costs an LDS read instead of a trip to memory
+  __shared__ uint32_t slots[IDX_GROUP * IDX_SLOTS];
   const size_t cbeg = (size_t)blockIdx.x * IDX_GROUP;
   const size_t cend = cbeg + IDX_GROUP < nchunks ? cbeg + IDX_GROUP : nchunks;
+  for (uint32_t i = threadIdx.x; i < (uint32_t)(cend - cbeg) * IDX_SLOTS; i += GROUP_THREADS) slots[i] = slot_result[cbeg * IDX_SLOTS + i];
+  __syncthreads();
+  if (threadIdx.x >= IDX_CAND) return;
   uint32_t state = threadIdx.x;
   uint64_t cnt = 0;
   bool bad = false;
   for (size_t c = cbeg; c < cend; ++c) {
-    const uint32_t e = chunk_table_entry(table, slot_result, c, state);
+    uint32_t e = table[c * IDX_CAND + state];
+    if (e != IDX_INVALID && (e & 0xFFFF) >= IDX_PENDING) {
+      const uint32_t r = slots[(c - cbeg) * IDX_SLOTS + (e & 0x7FFF)];
+      e = r == IDX_INVALID ? IDX_INVALID : ((((e >> 16) + (r >> 16)) << 16) | (r & 0xFFFF));
+    }
     if (e == IDX_INVALID) {
       bad = true;
       break;
