@@ -333,9 +333,10 @@ constexpr uint64_t IDX_INVALID64 = ~0ull;
 // crosses the boundary is a "survivor": survivors arriving at the same byte share one of the chunk's IDX_SLOTS slots,
 // kernel A' walks each slot to the end of the chunk (one lane per slot, all chunks of the stream at once), and the
 // table keeps (records so far, slot) for the candidates that end in a slot.
-// res[] words: (records << 16) | target, target < 1024: continue at that candidate, 1024 <= target < 0x8000: done, the
-// walk left the chunk target - 1024 bytes into the next one, target >= 0x8000: continues in slot target - 0x8000.
-constexpr uint32_t IDX_DONE = 1024;
+// res[] and table words: (records << 16) | target; target < 0x4000: done, the walk left the chunk `target` bytes into
+// the next one; target = 0x4000 + f: continue at candidate f (inside kernel A only); target = 0x8000 + s: continues in
+// slot s.
+constexpr uint32_t IDX_LINK = 0x4000;
 constexpr uint32_t IDX_PENDING = 0x8000;
 #ifndef SC_IDX_SLOTS
 #define SC_IDX_SLOTS 8
@@ -355,7 +356,7 @@ __global__ __launch_bounds__(CAND_THREADS) void k_index_candidates(const uint8_t
   // bound by instruction issue, about a thousand instructions per chunk; several chunks per workgroup, one per
   // wave, measured the same.)
   __shared__ u32x4 window[(WINDOW + 15) / 16];
-  __shared__ uint32_t res[IDX_CAND];
+  __shared__ __attribute__((aligned(16))) uint32_t res[IDX_CAND + 3];
   __shared__ uint16_t lists[IDX_CAND + 1];  // roots from the front, links from the back (a candidate is one or neither)
   const uint32_t lane = threadIdx.x;
   const size_t chunk = blockIdx.x;
@@ -384,39 +385,66 @@ __global__ __launch_bounds__(CAND_THREADS) void k_index_candidates(const uint8_t
     if (j < win) by[j] = tail;
   }
   wave_lds_fence();
-  // every lane counts the roots and links among its own candidates, one prefix sum over the wave gives it its
-  // places in the two lists (both counts in one word)
+  // every lane counts the roots and links among its own candidates (bit j of rootbits / linkbits: its j-th one), one
+  // prefix sum over the wave gives it its places in the two lists (both counts in one word)
   constexpr int PER_LANE = (IDX_CAND + CAND_THREADS - 1) / CAND_THREADS;
-  uint32_t width[PER_LANE];
-#pragma unroll
-  for (int k = 0; k < PER_LANE; ++k) {
-    const uint32_t f = lane + k * CAND_THREADS;
-    width[k] = f < IDX_CAND && f < len ? by[f] : 0xFF;
-  }
   uint32_t rootbits = 0, linkbits = 0;
-#pragma unroll
-  for (int k = 0; k < PER_LANE; ++k) {
-    const uint32_t f = lane + k * CAND_THREADS;
-    if (f < IDX_CAND) {
-      uint32_t word = IDX_INVALID;
-      if (f >= len) {
-        word = IDX_DONE + (f - len);  // the chunk is shorter than the candidate window
+  const bool whole = len >= 2 * (uint32_t)IDX_CAND;  // no first step leaves the chunk: all but the last chunk of a stream
+  if (whole) {
+    // lane l takes candidates 8 l .. 8 l + 7 (and lane 0 the 513th).  Seven of eight bytes are no width bytes: all
+    // eight are sorted out at once (bit 7 of a byte of `over` is set when the byte is above 32), the entries are
+    // written as invalid with two 16-byte stores, and only the valid ones are looked at one by one.
+    const uint64_t x = *reinterpret_cast<const uint64_t *>(by + 8 * lane);
+    auto valid_nibble = [](uint32_t w) {
+      const uint32_t over = (((w & 0x7F7F7F7Fu) + 0x5F5F5F5Fu) | w) & 0x80808080u;
+      return ((((~over) >> 7) & 0x01010101u) * 0x01020408u) >> 24;  // bits 7, 15, 23, 31 gathered into bits 0..3
+    };
+    uint32_t valid = valid_nibble((uint32_t)x) | (valid_nibble((uint32_t)(x >> 32)) << 4);
+    const u32x4 none = {IDX_INVALID, IDX_INVALID, IDX_INVALID, IDX_INVALID};
+    reinterpret_cast<u32x4 *>(res)[2 * lane] = none;
+    reinterpret_cast<u32x4 *>(res)[2 * lane + 1] = none;
+    while (valid) {
+      const uint32_t j = (uint32_t)__ffs((int)valid) - 1;
+      valid &= valid - 1;
+      const uint32_t f = 8 * lane + j, nf = f + 1 + 16 * ((uint32_t)(x >> (8 * j)) & 0xFF);
+      if (nf < (uint32_t)IDX_CAND) {
+        res[f] = (1u << 16) | IDX_LINK | nf;
+        linkbits |= 1u << j;
       } else {
-        const uint32_t b = width[k];
-        const uint32_t nf = f + 1 + 16 * b;
-        if (b > 32) {
-        } else if (nf >= len) {
-          word = (1u << 16) | (IDX_DONE + nf - len);
-        } else if (nf < IDX_CAND) {
-          word = (1u << 16) | nf;
-          linkbits |= 1u << k;
-        } else {
-          rootbits |= 1u << k;  // res[f] comes from the walk below
-        }
+        rootbits |= 1u << j;  // res[f] comes from the walk below
       }
-      res[f] = word;
+    }
+    if (lane == 0) {
+      res[IDX_CAND - 1] = IDX_INVALID;
+      if (by[IDX_CAND - 1] <= 32) rootbits |= 1u << 8;
+    }
+  } else {
+    uint32_t width[PER_LANE];
+#pragma unroll
+    for (int k = 0; k < PER_LANE; ++k) {
+      const uint32_t f = lane + k * CAND_THREADS;
+      width[k] = f < IDX_CAND && f < len ? by[f] : 0xFF;
+    }
+#pragma unroll
+    for (int k = 0; k < PER_LANE; ++k) {  // lane l takes candidates l, l + 64, ...
+      const uint32_t f = lane + k * CAND_THREADS;
+      const uint32_t b = width[k];  // 0xFF outside the chunk or the window
+      const uint32_t nf = f + 1 + 16 * b;
+      const bool valid = b <= 32, leaves = nf >= len;
+      const bool link = valid && !leaves && nf < (uint32_t)IDX_CAND;
+      const bool root = valid && !leaves && nf >= (uint32_t)IDX_CAND;  // res[f] comes from the walk below
+      uint32_t word = IDX_INVALID;
+      word = valid && leaves ? ((1u << 16) | (nf - len)) : word;
+      word = link ? ((1u << 16) | IDX_LINK | nf) : word;
+      word = f >= len ? f - len : word;  // the chunk is shorter than the candidate window
+      linkbits |= (uint32_t)link << k;
+      rootbits |= (uint32_t)root << k;
+      if (f < (uint32_t)IDX_CAND) res[f] = word;
     }
   }
+  auto candidate = [&](int j) -> uint32_t {  // the lane's j-th candidate
+    return whole ? (j == 8 ? (uint32_t)IDX_CAND - 1 : 8 * lane + (uint32_t)j) : lane + (uint32_t)j * CAND_THREADS;
+  };
   const uint32_t mine = (uint32_t)__popc(rootbits) | ((uint32_t)__popc(linkbits) << 16);
   uint32_t incl = mine;
   incl += dpp0<DPP_ROW_SHR1>(incl);
@@ -432,12 +460,12 @@ __global__ __launch_bounds__(CAND_THREADS) void k_index_candidates(const uint8_t
   while (rootbits) {
     const int k = __ffs((int)rootbits) - 1;
     rootbits &= rootbits - 1;
-    lists[root_at++] = (uint16_t)(lane + k * CAND_THREADS);
+    lists[root_at++] = (uint16_t)candidate(k);
   }
   while (linkbits) {
     const int k = __ffs((int)linkbits) - 1;
     linkbits &= linkbits - 1;
-    lists[IDX_CAND - link_at++] = (uint16_t)(lane + k * CAND_THREADS);
+    lists[IDX_CAND - link_at++] = (uint16_t)candidate(k);
   }
   wave_lds_fence();
   uint32_t slot_pos[IDX_SLOTS];
@@ -494,7 +522,7 @@ __global__ __launch_bounds__(CAND_THREADS) void k_index_candidates(const uint8_t
       walking = false;
     }
     if (t < total)
-      res[r] = dead ? IDX_INVALID : ((cnt << 16) | (walking ? IDX_PENDING + (uint32_t)slot : IDX_DONE + p - len));
+      res[r] = dead ? IDX_INVALID : ((cnt << 16) | (walking ? IDX_PENDING + (uint32_t)slot : p - len));
   }
   if (lane < IDX_SLOTS) {
     uint32_t v = IDX_INVALID;
@@ -516,7 +544,7 @@ __global__ __launch_bounds__(CAND_THREADS) void k_index_candidates(const uint8_t
       const uint32_t tw = res[w & 0x3FF];
       const bool dead = tw == IDX_INVALID;
       w = dead ? IDX_INVALID : ((((w >> 16) + (tw >> 16)) << 16) | (tw & 0xFFFF));
-      const bool still = have && !dead && (tw & 0xFFFF) < IDX_DONE;
+      const bool still = have && !dead && (tw & IDX_LINK);
       const uint64_t smask = __ballot(still);
       wave_lds_fence();  // every lane has read res[] and links[] of this batch (and of the rounds before)
       if (have) res[f] = w;
@@ -534,9 +562,8 @@ __global__ __launch_bounds__(CAND_THREADS) void k_index_candidates(const uint8_t
   }
 #pragma unroll
   for (int k = 0; k < PER_LANE; ++k) {
-    const uint32_t f = lane + k * CAND_THREADS, w = out[k];
-    if (f < IDX_CAND)
-      table[chunk * IDX_CAND + f] = (w == IDX_INVALID || (w & 0xFFFF) >= IDX_PENDING) ? w : (w - IDX_DONE);
+    const uint32_t f = lane + k * CAND_THREADS;
+    if (f < IDX_CAND) table[chunk * IDX_CAND + f] = out[k];
   }
 }
 
