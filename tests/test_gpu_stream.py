@@ -450,3 +450,58 @@ def test_decode_large_stream_every_alignment(dev, d1):
     assert res.tolist()[0] == nblk and torch.equal(out[: nblk * 128], ids)
     surplus = out[nblk * 128:]
     assert (surplus == (ids[-1] if d1 else 0)).all()
+
+
+def test_index_soak(dev, orc):
+    """Eighty synthetic streams of many shapes (natural, narrow, wide, zero-width runs; payloads that are random, look
+    like width bytes, repeat the record's own width, or are one constant; a third with a bad width byte, a third cut
+    short), each compared with the CPU walk: status, record count, and width / offset of every record in front of the
+    first bad byte (tools/exp/index_soak.py is the long form of this test)."""
+    import torch
+
+    rng = np.random.default_rng(20260)
+    menus = ([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 14, 17, 20, 24, 32], [0, 0, 1, 1, 1, 2, 3], [28, 30, 31, 32, 32],
+             [0, 0, 0, 0, 0, 0, 0, 1], [0, 0, 1, 2, 3, 5, 8, 13, 20, 31, 32])
+    for it in range(80):
+        target = int(rng.choice([17, 513, 1539, 16384, 16385, 40000, 3 * 16384 - 1, 300000, 1 << 20]))
+        if it % 2:
+            target = int(rng.integers(1, target + 1))
+        widths, total = [], 0
+        while True:
+            w = int(rng.choice(menus[it % 5]))
+            if total + 1 + 16 * w > target:
+                break
+            widths.append(w)
+            total += 1 + 16 * w
+        widths = np.array(widths + [0] * (target - total), np.uint8)
+        pos = np.concatenate([[0], np.cumsum(1 + 16 * widths.astype(np.int64))])[:-1]
+        fill = it % 4
+        if fill == 0:
+            stream = rng.integers(0, 256, target, dtype=np.uint8)
+        elif fill == 1:
+            stream = rng.integers(0, 33, target, dtype=np.uint8)
+        elif fill == 2:
+            stream = np.repeat(widths, 1 + 16 * widths.astype(np.int64))
+        else:
+            stream = np.full(target, it % 3, np.uint8)
+        stream[pos] = widths
+        damage = it % 3
+        if damage == 1:
+            stream[int(pos[int(rng.integers(0, widths.size))])] = int(rng.integers(33, 256))
+        elif damage == 2 and target > 1:
+            stream = stream[: int(rng.integers(1, target))]
+        cap = widths.size + 3
+        n, _, _, status = orc.stream_walk(stream, cap)
+        bits, off, res = dev.stream_index(to_dev(stream), cap)
+        res = res.tolist()
+        assert res[2] == (1 if status else 0), it
+        if status == 0:
+            assert res[:2] == [n, stream.size - n], it
+        p, good = 0, 0
+        while p < stream.size and stream[p] <= 32 and p + 1 + 16 * int(stream[p]) <= stream.size:
+            p += 1 + 16 * int(stream[p])
+            good += 1
+        good = min(good, cap)
+        gb, go = bits.cpu().numpy()[:good], off.cpu().numpy()[:good]
+        want = np.concatenate([[0], np.cumsum(1 + 16 * gb.astype(np.int64))])[:-1] if good else np.zeros(0, np.int64)
+        assert np.array_equal(gb, stream[want]) and np.array_equal(go, want - np.arange(good)), it
