@@ -801,6 +801,8 @@ __global__ __launch_bounds__(EMIT_THREADS) void k_index_emit(const uint8_t *stre
   uint32_t starts[IDX_SLOTS];
 #pragma unroll
   for (int k = 0; k < IDX_SLOTS; ++k) starts[k] = ok ? slot_start[c * IDX_SLOTS + k] : IDX_INVALID;
+  // (Staging the head of the chunk in LDS for these first steps, as the candidates kernel does, doubled the kernel's
+  // time: 95 MB more to fetch for a dozen steps per chunk.)
   // (every lane of the row takes the same path through this function)  Records are handed to the lanes of the row
   // in turn and written sixteen at a time, so that the loads of the walk do not queue behind single stores.
   uint32_t held = 0, my_b = 0;
