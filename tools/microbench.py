@@ -116,6 +116,14 @@ def stream(n, nblk, reps):
         "maxbitsd1": (lambda: codec.maxbitsd1(ids, initvalue=0, initvalues_out=seeds), 517 * nblk),
         "payload_offsets": (lambda: codec.payload_offsets(bits), 9 * nblk),
     }
+    # compress() as one call
+    ws_k = torch.empty(max(16, L.simdcomp_hip_stream_compress_workspace(nblk)), dtype=torch.uint8, device=dev)
+    nb_k = torch.zeros(1, dtype=torch.int64, device=dev)
+    strm3 = torch.empty(513 * nblk if nblk < (1 << 21) else T + nblk + 1024, dtype=torch.uint8, device=dev)
+    binding.check(L.simdcomp_hip_stream_compress(1, 0, P(ids), nblk, P(strm3), P(nb_k), P(ws_k), st), "stream_compress")
+    assert not check or (int(nb_k.item()) == T + nblk and torch.equal(strm3[:T + nblk], strm)), "stream_compress differs"
+    rows["stream_compress"] = (lambda: L.simdcomp_hip_stream_compress(1, 0, P(ids), nblk, P(strm3), P(nb_k), P(ws_k), st),
+                               512 * nblk + T + nblk)
     # the decode loop as one call (record index + chained decode straight from the bytes)
     ws_d = torch.empty(max(16, L.simdcomp_hip_stream_decode_workspace(T + nblk, nblk)), dtype=torch.uint8, device=dev)
     for mode, name in ((1, "stream_decode"), (0, "stream_decode_plain")):
