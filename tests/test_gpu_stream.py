@@ -505,3 +505,41 @@ def test_index_soak(dev, orc):
         gb, go = bits.cpu().numpy()[:good], off.cpu().numpy()[:good]
         want = np.concatenate([[0], np.cumsum(1 + 16 * gb.astype(np.int64))])[:-1] if good else np.zeros(0, np.int64)
         assert np.array_equal(gb, stream[want]) and np.array_equal(go, want - np.arange(good)), it
+
+
+def test_index_respects_max_blocks(dev, orc):
+    """max_blocks smaller than the number of records: exactly max_blocks widths and offsets are written (guard zones
+    on both sides of the two arrays stay untouched) and d_result still counts every record."""
+    import torch
+
+    from simdcomp_amd import binding as B
+
+    L = B.lib()
+    rng = np.random.default_rng(5)
+    guard = 64
+    for target in (5000, 16384, 70000, 400000, 1 << 20):
+        widths, total = [], 0
+        while True:
+            w = int(rng.choice([0, 1, 2, 3, 5, 8, 13, 20, 32]))
+            if total + 1 + 16 * w > target:
+                break
+            widths.append(w)
+            total += 1 + 16 * w
+        widths = np.array(widths + [0] * (target - total), np.uint8)
+        pos = np.concatenate([[0], np.cumsum(1 + 16 * widths.astype(np.int64))])[:-1]
+        stream = rng.integers(0, 256, target, dtype=np.uint8)
+        stream[pos] = widths
+        n = widths.size
+        for cap in (0, 1, n // 3, n - 1):
+            bits = torch.full((cap + 2 * guard,), 0xAB, dtype=torch.uint8, device="cuda")
+            off = torch.full((cap + 2 * guard,), -7, dtype=torch.int64, device="cuda")
+            res = torch.zeros(3, dtype=torch.int64, device="cuda")
+            ws = torch.empty(L.simdcomp_hip_stream_index_workspace(target), dtype=torch.uint8, device="cuda")
+            B.check(L.simdcomp_hip_stream_index(B.ptr(to_dev(stream)), target, cap, bits[guard:].data_ptr(), off[guard:].data_ptr(),
+                                                B.ptr(res), B.ptr(ws), torch.cuda.current_stream().cuda_stream), "stream_index")
+            torch.cuda.synchronize()
+            assert res.tolist() == [n, target - n, 0], (target, cap)
+            assert (bits[:guard] == 0xAB).all() and (bits[guard + cap:] == 0xAB).all(), (target, cap)
+            assert (off[:guard] == -7).all() and (off[guard + cap:] == -7).all(), (target, cap)
+            assert np.array_equal(bits[guard:guard + cap].cpu().numpy(), widths[:cap]), (target, cap)
+            assert np.array_equal(off[guard:guard + cap].cpu().numpy(), (pos - np.arange(n))[:cap]), (target, cap)
