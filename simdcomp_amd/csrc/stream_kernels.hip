@@ -349,7 +349,7 @@ constexpr int IDX_PROBE = SC_IDX_PROBE;
 constexpr int CAND_THREADS = 64;
 
 __global__ __launch_bounds__(CAND_THREADS) void k_index_candidates(const uint8_t *stream, size_t nbytes, uint32_t *table,
-                                                                   uint32_t *slot_start) {
+                                                                   uint32_t *slot_start, uint32_t *pool_next) {
   constexpr uint32_t BOUNDARY = IDX_CAND * IDX_PROBE;  // roots walk until they cross this byte
   constexpr uint32_t WINDOW = BOUNDARY;                // so this much of the chunk is staged
   // (the workgroup is one wave: a wave-level fence is all the synchronisation the LDS arrays need.  The kernel is
@@ -360,6 +360,7 @@ __global__ __launch_bounds__(CAND_THREADS) void k_index_candidates(const uint8_t
   __shared__ uint16_t lists[IDX_CAND + 1];  // roots from the front, links from the back (a candidate is one or neither)
   const uint32_t lane = threadIdx.x;
   const size_t chunk = blockIdx.x;
+  if (chunk == 0 && lane == 0) *pool_next = 0;  // the survivors kernel, which runs after this one, hands out logs from 0
   const size_t c0 = chunk * IDX_CHUNK;
   const uint8_t *src = stream + c0;
   const uint32_t len = (uint32_t)(nbytes - c0 < (size_t)IDX_CHUNK ? nbytes - c0 : (size_t)IDX_CHUNK);
@@ -920,9 +921,8 @@ hipError_t launch_stream_index(const uint8_t *stream, size_t nbytes, size_t max_
   uint8_t *logs = ws;
   const size_t nslots = nchunks * IDX_SLOTS, nregions = idx_log_regions(nchunks);
   if (nregions > 0xFFFFFFF0ull) return hipErrorInvalidValue;  // (a stream of more than 40 TiB)
-  hipError_t e = hipMemsetAsync(pool_next, 0, sizeof(uint32_t), st);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_index_candidates, dim3((unsigned)nchunks), dim3(CAND_THREADS), 0, st, stream, nbytes, table, slot_start);
+  hipLaunchKernelGGL(k_index_candidates, dim3((unsigned)nchunks), dim3(CAND_THREADS), 0, st, stream, nbytes, table, slot_start,
+                     pool_next);
   hipLaunchKernelGGL(k_index_survivors, dim3((unsigned)((nslots + SURV_THREADS - 1) / SURV_THREADS)), dim3(SURV_THREADS), 0, st,
                      stream, nbytes, nslots, slot_start, slot_result, slot_log, pool_next, (uint32_t)nregions, logs);
   hipLaunchKernelGGL(k_index_groups, dim3((unsigned)ngroups), dim3(GROUP_THREADS), 0, st, table, slot_result, nchunks, gtable);
