@@ -426,7 +426,7 @@ int simdcomp_hip_stream_index(const void *d_stream, size_t stream_bytes, size_t 
   if (stream_bytes && max_blocks && (!d_bits || !d_payload_offsets)) return fail(SIMDCOMP_HIP_ENULL, "NULL output array");
   if (!aligned16(d_workspace)) return fail(SIMDCOMP_HIP_EALIGN, "workspace not 16-byte aligned");
   return hip_result(sc::launch_stream_index(static_cast<const uint8_t *>(d_stream), stream_bytes, max_blocks, d_bits,
-                                            d_payload_offsets, d_result, d_workspace, as_stream(stream)),
+                                            d_payload_offsets, d_result, d_workspace, /*clear_tail=*/false, as_stream(stream)),
                     "stream index launch");
 }
 
@@ -477,9 +477,11 @@ int simdcomp_hip_stream_decode(int mode, uint32_t initvalue, const void *d_strea
   uint32_t *seeds = reinterpret_cast<uint32_t *>(ws + up256(nblocks) + up256(8 * nblocks));
   uint8_t *index_ws = ws + up256(nblocks) + up256(8 * nblocks) + up256(4 * nblocks);
   uint8_t *chain_ws = index_ws + up256(sc::stream_index_workspace_bytes(stream_bytes));
-  // a stream with fewer records than nblocks leaves the rest as zero-width blocks at offset 0 (d_result[0] tells)
-  if (hipError_t e = hipMemsetAsync(ws, 0, up256(nblocks) + up256(8 * nblocks), as_stream(stream))) return hip_result(e, "memset");
-  int rc = simdcomp_hip_stream_index(d_stream, stream_bytes, nblocks, bits, off, d_result, index_ws, stream);
+  // a stream with fewer records than nblocks leaves the rest as zero-width blocks at offset 0 (d_result[0] tells): the
+  // index clears exactly those entries (all of them before it writes what it finds, when the stream is bad)
+  int rc = hip_result(sc::launch_stream_index(static_cast<const uint8_t *>(d_stream), stream_bytes, nblocks, bits, off, d_result,
+                                              index_ws, /*clear_tail=*/true, as_stream(stream)),
+                      "stream index launch");
   if (rc) return rc;
   if (mode == SIMDCOMP_HIP_D1) {
     if ((rc = simdcomp_hip_chain_offsets(initvalue, d_stream, off, bits, nblocks, 1, seeds, chain_ws, stream))) return rc;

@@ -28,8 +28,9 @@ hipError_t launch_stream_bytes(const uint64_t *payload_bytes, size_t nblocks, ui
 size_t stream_index_workspace_bytes(size_t stream_bytes);
 // result[0] = records found, result[1] = arena bytes (16 * sum of widths), result[2] = 0 when the stream parsed
 // cleanly to its last byte, 1 otherwise (a width byte above 32 or a truncated last record).  At most max_blocks
-// entries of bits[] / off[] are written.
+// entries of bits[] / off[] are written; with clear_tail the entries among those max_blocks that belong to no record
+// (a short stream; a bad one beyond its good part) are set to zero as well, otherwise they are left alone.
 hipError_t launch_stream_index(const uint8_t *stream, size_t stream_bytes, size_t max_blocks, uint8_t *bits, uint64_t *off,
-                               uint64_t *result, void *workspace, hipStream_t st);
+                               uint64_t *result, void *workspace, bool clear_tail, hipStream_t st);
 
 }  // namespace sc

@@ -779,6 +779,17 @@ __global__ __launch_bounds__(64) void k_index_chunk_entries(const uint32_t *tabl
   }
 }
 
+// For the one-call decode: entries the emit pass will not write (a stream with fewer records than max_blocks; every
+// entry when the stream is bad, the emit pass then writes those in front of the bad byte) read as zero-width blocks
+// at offset 0.  Runs between the spine, which knows the record count, and the emit pass; usually finds nothing to do.
+__global__ __launch_bounds__(256) void k_index_clear_tail(const uint64_t *result, size_t max_blocks, uint8_t *bits, uint64_t *off) {
+  const size_t first = result[2] ? 0 : (result[0] < max_blocks ? result[0] : max_blocks);
+  for (size_t i = first + (size_t)blockIdx.x * 256 + threadIdx.x; i < max_blocks; i += (size_t)gridDim.x * 256) {
+    bits[i] = 0;
+    off[i] = 0;
+  }
+}
+
 constexpr int EMIT_THREADS = 64;
 constexpr int EMIT_LANES = 16;  // lanes per chunk: one DPP row
 
@@ -894,8 +905,14 @@ size_t stream_index_workspace_bytes(size_t nbytes) {
 }
 
 hipError_t launch_stream_index(const uint8_t *stream, size_t nbytes, size_t max_blocks, uint8_t *bits, uint64_t *off,
-                               uint64_t *result, void *workspace, hipStream_t st) {
-  if (nbytes == 0) return hipMemsetAsync(result, 0, 3 * sizeof(uint64_t), st);
+                               uint64_t *result, void *workspace, bool clear_tail, hipStream_t st) {
+  if (nbytes == 0) {
+    if (clear_tail && max_blocks) {
+      if (hipError_t e = hipMemsetAsync(bits, 0, max_blocks, st)) return e;
+      if (hipError_t e = hipMemsetAsync(off, 0, 8 * max_blocks, st)) return e;
+    }
+    return hipMemsetAsync(result, 0, 3 * sizeof(uint64_t), st);
+  }
   const size_t nchunks = idx_chunks(nbytes), ngroups = idx_groups(nchunks), nsupers = idx_supers(ngroups);
   uint8_t *ws = static_cast<uint8_t *>(workspace);
   uint32_t *table = reinterpret_cast<uint32_t *>(ws);
@@ -928,6 +945,7 @@ hipError_t launch_stream_index(const uint8_t *stream, size_t nbytes, size_t max_
   hipLaunchKernelGGL(k_index_groups, dim3((unsigned)ngroups), dim3(GROUP_THREADS), 0, st, table, slot_result, nchunks, gtable);
   hipLaunchKernelGGL(k_index_supers, dim3((unsigned)nsupers), dim3(GROUP_THREADS), 0, st, gtable, ngroups, stable);
   hipLaunchKernelGGL(k_index_spine, dim3(1), dim3(1), 0, st, stable, nsupers, nbytes, sentry, result);
+  if (clear_tail && max_blocks) hipLaunchKernelGGL(k_index_clear_tail, dim3(512), dim3(256), 0, st, result, max_blocks, bits, off);
   hipLaunchKernelGGL(k_index_group_entries, dim3((unsigned)((nsupers + 63) / 64)), dim3(64), 0, st, gtable, ngroups, nsupers,
                      sentry, gentry);
   hipLaunchKernelGGL(k_index_chunk_entries, dim3((unsigned)((ngroups + 63) / 64)), dim3(64), 0, st, table, slot_result, nchunks, ngroups,
