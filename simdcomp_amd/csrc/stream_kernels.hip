@@ -312,7 +312,7 @@ hipError_t launch_stream_unbuild(const uint8_t *stream, const uint64_t *off, con
 //   E  every chunk writes width and arena offset of each record of its true chain: the few records in front of the
 //      logged walk by walking, the rest from the log.
 // (Staging whole chunks in LDS for A and walking the true chain again in E, as this code did at first, cost 0.58 ms
-// and 0.22 ms per GiB of stream; A + A' take 0.14 + 0.27 ms, E 0.06 ms.)
+// and 0.22 ms per GiB of stream; A + A' take 0.13 + 0.25 ms, E 0.065 ms.)
 // A width byte above 32 ends a walk as invalid; the true chain hitting one is reported in result[2].
 #ifndef SC_IDX_CHUNK
 #define SC_IDX_CHUNK 16384
