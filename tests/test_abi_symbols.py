@@ -196,3 +196,28 @@ def test_public_headers_compile_as_plain_c_and_cxx(tmp_path):
         cpp.write_text(src)
         r = subprocess.run([cxx, "-std=c++11", "-Wall", "-Werror", "-I", inc, "-fsyntax-only", str(cpp)], capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
+
+
+def test_workspace_sizes_are_consistent():
+    """The workspace-size functions are plain host arithmetic: multiples of 256, never shrinking with the input, large
+    enough for what the kernels keep there (per 16 KiB chunk of stream: a table of 513 words and 1.5 logs of 1 KiB),
+    and the one-call decode's workspace holds the index's and the chain's."""
+    L = binding.lib()
+    prev = 0
+    for nbytes in (0, 1, 513, 16384, 16385, 1 << 20, (1 << 30) + 7, 1 << 36, 1 << 40):
+        w = L.simdcomp_hip_stream_index_workspace(nbytes)
+        chunks = (nbytes + 16383) // 16384
+        assert w % 256 == 0 and w >= prev
+        assert w >= chunks * (513 * 4 + 1536)
+        assert w <= max(8192, nbytes) * 0.3 + (1 << 20), nbytes  # about a quarter of the stream
+        prev = w
+        nblk = nbytes // 100 + 1
+        d = L.simdcomp_hip_stream_decode_workspace(nbytes, nblk)
+        assert d >= w + L.simdcomp_hip_chain_workspace(nblk) + 13 * nblk
+    prev = 0
+    for nblk in (0, 1, 4095, 4096, 4097, 1 << 23, 1 << 29):
+        for f in (L.simdcomp_hip_payload_offsets_workspace, L.simdcomp_hip_chain_workspace, L.simdcomp_hip_stream_compress_workspace):
+            assert f(nblk) >= 0
+        c = L.simdcomp_hip_stream_compress_workspace(nblk)
+        assert c >= prev and c >= 9 * nblk
+        prev = c
