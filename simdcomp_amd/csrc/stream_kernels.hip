@@ -231,7 +231,10 @@ hipError_t launch_chain_offsets(uint32_t init, const void *payload, const uint64
 // One block per half-wave, thread k < b moves payload vector k with one 16-byte load and one 16-byte store; the
 // stream side is at an arbitrary byte address.  U blocks per half-wave, loads first (clamped, never predicated),
 // stores after.  TO_STREAM also writes the width bytes.
-constexpr int COPY_U = 4;
+#ifndef SC_COPY_U
+#define SC_COPY_U 8
+#endif
+constexpr int COPY_U = SC_COPY_U;
 
 template <bool TO_STREAM>
 __global__ __launch_bounds__(256) void k_stream_copy(const uint8_t *src, uint8_t *dst, const uint64_t *off, const uint8_t *bits,

@@ -10,6 +10,6 @@ for v in "$@"; do
   grep -h "^stream " /root/repo/gpurun_out/ab_$v.log | python3 -c "
 import sys, json
 d = json.loads(sys.stdin.read().split(' ', 1)[1])
-print({k: v['ms'] for k, v in d.items() if isinstance(v, dict) and k in ('stream_index', 'chain_offsets', 'unpack_stream', 'stream_decode', 'stream_decode_plain', 'stream_compress')})"
+print({k: v['ms'] for k, v in d.items() if isinstance(v, dict) and k in ('stream_index', 'chain_offsets', 'unpack_stream', 'stream_decode', 'stream_decode_plain', 'stream_compress', 'stream_build', 'stream_unbuild')})"
   python3 /root/repo/tools/kstats.py /root/repo/gpurun_out/ab_$v | grep "k_index\|k_compress" | cut -c1-40,100-140
 done
