@@ -721,13 +721,21 @@ def main():
     if a.selftest:
         return selftest(a, rank, world)
 
+    # SIMDCOMP_BENCH_SHARE_GPU=1: every rank uses GPU 0 and the process group runs over gloo (RCCL refuses two ranks
+    # on one device).  Only for rehearsing the N > 1 code path on a one-GPU machine; the line says so.
+    share_gpu = os.environ.get("SIMDCOMP_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # under torch.distributed.run (RANK set) the process group is always created, also for one rank, so that the
     # same code path runs at every N
     distributed = world > 1 or "RANK" in os.environ
     if distributed:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         assert dist.get_world_size() == a.gpus, (dist.get_world_size(), a.gpus)
 
     # block-range shard of the global corpus (weak scaling: 2^log2n docIDs per GPU)
@@ -799,6 +807,8 @@ def main():
             how = "torch.distributed.run"
         else:
             how = "bench.py launcher, one child process per GPU" if distributed else "single process"
+        if share_gpu:
+            how += "; REHEARSAL: all ranks share GPU 0, process group over gloo (not a scaling measurement)"
         line = {
             "metric": "device-resident decoded int32/s (simdunpackd1, b=1..32)",
             "value": ints_per_step * a.steps / elapsed,

@@ -54,3 +54,22 @@ def test_failing_rank_fails_the_launch():
     out = run_selftest(2, env_extra={"SIMDCOMP_HIP_LIB": "/nonexistent/libsimdcomp_hip.so"})
     assert out.returncode != 0
     assert "not found" in out.stderr
+
+
+@pytest.mark.gpu
+def test_two_ranks_share_one_gpu():
+    """The N > 1 path of the benchmark itself (shards, per-rank legs, gathers, verification all-reduce) with both
+    ranks on GPU 0 and the process group over gloo: a rehearsal for machines with one GPU, not a measurement."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["SIMDCOMP_BENCH_SHARE_GPU"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--log2n", "22", "--steps", "2",
+                          "--warmup", "1", "--no-h2h"], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    doc = json.loads(lines[0])
+    assert doc["n_gpus"] == 2 and "REHEARSAL" in doc["config"]["launch"]
+    assert doc["config"]["ints_per_gpu"] == 1 << 22
+    assert doc["verification"]["decode_mismatches"] == 0
+    assert len(doc["roofline"]["per_rank_frac"]) == 2
+    assert len(doc["encode"]["per_rank_value"]) == 2 and doc["encode"]["widths_with_wrong_bytes"] == 0
