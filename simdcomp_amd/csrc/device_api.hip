@@ -227,7 +227,7 @@ int simdcomp_hip_payload_offsets(const uint8_t *d_bits, size_t nblocks, uint64_t
 namespace {
 constexpr size_t SCRATCH_BYTES = (size_t)1 << 20;
 constexpr int SCRATCH_MAX_DEVICES = 64;
-__device__ __align__(256) unsigned char scratch[SCRATCH_BYTES];
+static __device__ __align__(256) unsigned char scratch[SCRATCH_BYTES];
 std::atomic<void *> g_scratch_ptr[SCRATCH_MAX_DEVICES];
 
 // Device address of `scratch` on the current device (every GPU holds its own copy at its own address).
