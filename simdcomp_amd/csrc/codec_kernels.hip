@@ -768,7 +768,11 @@ __global__ __launch_bounds__(BS) void k_pack_fast(PackArgs a) {
           if constexpr (SC_NT_MIXED) __builtin_nontemporal_store(val, reinterpret_cast<u32x4_u *>(pbase[u] + 16 * w));
           else *reinterpret_cast<u32x4_u *>(pbase[u] + 16 * w) = val;
         }
-        if (a.stream_layout && k == 0) pbase[u][-1] = (uint8_t)bu;
+        // (the width byte leaves the way the payload next to it does: 0.908 -> 0.894 ms at 2^30 integers)
+        if (a.stream_layout && k == 0) {
+          if constexpr (SC_NT_MIXED) __builtin_nontemporal_store((uint8_t)bu, pbase[u] - 1);
+          else pbase[u][-1] = (uint8_t)bu;
+        }
       }
     }
     if constexpr (MODE == MODE_D1) {

@@ -228,61 +228,115 @@ hipError_t launch_chain_offsets(uint32_t init, const void *payload, const uint64
 // ---------------------------------------------------------------------------
 // [b][payload] stream <-> aligned arena
 // ---------------------------------------------------------------------------
-// One block per half-wave, thread k < b moves payload vector k with one 16-byte load and one 16-byte store; the
-// stream side is at an arbitrary byte address.  U blocks per half-wave, loads first (clamped, never predicated),
-// stores after.  TO_STREAM also writes the width bytes.
-#ifndef SC_COPY_U
-#define SC_COPY_U 8
+// A wave takes 64 consecutive blocks, lane l the width and offset of block l, and moves their payload vectors
+// densely: vector i of the wave's V = b_0 + ... + b_63 vectors goes to lane i mod 64 of round i / 64, so every load
+// and store instruction moves 64 vectors whatever the widths are.  (With one block per half-wave and lane k < b
+// moving vector k, as this kernel worked before, a quarter of the lanes were busy at 7.5 bits per integer and the
+// copy was bound by the rate of memory instructions: 16 cycles of the texture addresser per 16-byte instruction of
+// a wave, busy lanes or not.)  The owner of vector i -- the block l with P_l <= i < P_l + b_l, P the exclusive scan of
+// the widths over the wave -- comes from a table in LDS: block l writes l + 1 at entry P_l, a running maximum over
+// the entries fills in the rest (one DPP scan per round, carried from round to round).  The owner's P and offset
+// travel through the LDS crossbar.  Loads of COPY_G rounds go out together, stores after; the stream side is at
+// an arbitrary byte address.  TO_STREAM also writes the width bytes.
+#ifndef SC_COPY_G
+#define SC_COPY_G 8
 #endif
-constexpr int COPY_U = SC_COPY_U;
+constexpr int COPY_G = SC_COPY_G;
+constexpr int COPY_WAVE_BLOCKS = 64;
+
+__device__ __forceinline__ uint32_t wave_scan_add_u32(uint32_t t) {
+  t += dpp0<DPP_ROW_SHR1>(t);
+  t += dpp0<DPP_ROW_SHR2>(t);
+  t += dpp0<DPP_ROW_SHR4>(t);
+  t += dpp0<DPP_ROW_SHR8>(t);
+  t += dpp0<DPP_ROW_BCAST15, 0xA>(t);
+  t += dpp0<DPP_ROW_BCAST31, 0xC>(t);
+  return t;
+}
+__device__ __forceinline__ uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
+__device__ __forceinline__ uint32_t wave_scan_max_u32(uint32_t t) {
+  t = umax(t, dpp0<DPP_ROW_SHR1>(t));
+  t = umax(t, dpp0<DPP_ROW_SHR2>(t));
+  t = umax(t, dpp0<DPP_ROW_SHR4>(t));
+  t = umax(t, dpp0<DPP_ROW_SHR8>(t));
+  t = umax(t, dpp0<DPP_ROW_BCAST15, 0xA>(t));
+  t = umax(t, dpp0<DPP_ROW_BCAST31, 0xC>(t));
+  return t;
+}
 
 template <bool TO_STREAM>
 __global__ __launch_bounds__(256) void k_stream_copy(const uint8_t *src, uint8_t *dst, const uint64_t *off, const uint8_t *bits,
                                                      size_t nblocks) {
-  constexpr int U = COPY_U;
+  constexpr int G = COPY_G;
+  constexpr int TABLE = 32 * COPY_WAVE_BLOCKS;  // most vectors 64 blocks can have
+  __shared__ u32x4 owner_mem[4][TABLE / 16];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int h = lane >> 5, k = lane & 31;
-  const size_t first = ((size_t)blockIdx.x * 4 + wv) * 2 * U + h;
-  uint32_t b[U];
-  uint64_t o[U];
-  u32x4 x[U];
-  {
-    // one coalesced load per array for the wave's 2 * U consecutive blocks (blocks past the end repeat the last one)
-    const size_t wb = ((size_t)blockIdx.x * 4 + wv) * 2 * U + (size_t)(lane % (2 * U));
-    const size_t mine = wb < nblocks ? wb : nblocks - 1;
-    hand_out<U>((uint32_t)bits[mine], h, b);
-    hand_out<U>(off[mine], h, o);
-  }
+  const size_t wb = ((size_t)blockIdx.x * 4 + wv) * COPY_WAVE_BLOCKS;
+  if (wb >= nblocks) return;  // (whole waves; there is no workgroup barrier in this kernel)
+  const size_t blk = wb + (size_t)lane;
+  const bool have = blk < nblocks;
+  const size_t bc = have ? blk : nblocks - 1;
+  uint32_t b = bits[bc];
+  const uint64_t o = off[bc];
+  b = b > 32 ? 32 : b;
+  b = have ? b : 0;
+  const uint32_t incl = wave_scan_add_u32(b);
+  const uint32_t P = incl - b;
+  const uint32_t V = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+  uint8_t *owner = reinterpret_cast<uint8_t *>(owner_mem[wv]);
+  owner_mem[wv][lane] = u32x4{0, 0, 0, 0};
+  owner_mem[wv][lane + 64] = u32x4{0, 0, 0, 0};
+  wave_lds_fence();
+  if (b) owner[P] = (uint8_t)(lane + 1);
+  wave_lds_fence();
+  uint32_t carry = 0;
+  for (uint32_t r0 = 0; r0 * 64 < V; r0 += G) {
+    u32x4 x[G];
+    uint64_t to[G];
+    bool act[G], head[G];
+    uint32_t wbyte[G];
 #pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const size_t blk = first + 2 * (size_t)u;
-    const size_t bc = blk < nblocks ? blk : nblocks - 1;
-    b[u] = b[u] > 32 ? 32 : b[u];
-    const uint32_t last = b[u] ? b[u] - 1 : 0;
-    const uint64_t from = o[u] + (TO_STREAM ? 0 : bc + 1) + 16 * ((uint32_t)k < last ? (uint32_t)k : last);
-    // a zero-width block has nothing to read, but its load is issued all the same (from 16 bytes that are always
-    // there): behind a branch each of the U loads would wait for the one before
-    uintptr_t at = reinterpret_cast<uintptr_t>(src + from);
-    at = (uint32_t)k > last ? (at & ~(uintptr_t)15) : at;  // idle lanes: an aligned address coalesces better
-    x[u] = SC_NT_COPY ? load_global_nt(b[u] ? at : reinterpret_cast<uintptr_t>(&g_nothing)) : load_global_at(b[u] ? at : reinterpret_cast<uintptr_t>(&g_nothing));
-  }
+    for (int g = 0; g < G; ++g) {
+      const uint32_t i = (r0 + g) * 64 + (uint32_t)lane;
+      uint32_t ow = owner[i < TABLE ? i : TABLE - 1];
+      ow = umax(wave_scan_max_u32(ow), carry);
+      carry = (uint32_t)__builtin_amdgcn_readlane((int)ow, 63);
+      act[g] = i < V;
+      const int l4 = (int)(ow ? ow - 1 : 0) * 4;  // the owner's lane, as the byte address the crossbar wants
+      const uint32_t Pl = (uint32_t)__builtin_amdgcn_ds_bpermute(l4, (int)P);
+      const uint64_t ol = ((uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute(l4, (int)(uint32_t)(o >> 32)) << 32) |
+                          (uint32_t)__builtin_amdgcn_ds_bpermute(l4, (int)(uint32_t)o);
+      const uint64_t in_arena = ol + 16 * (uint64_t)(i - Pl);
+      const uint64_t in_stream = in_arena + wb + (uint64_t)(l4 >> 2) + 1;
+      to[g] = TO_STREAM ? in_stream : in_arena;
+      const uintptr_t from = reinterpret_cast<uintptr_t>(src) + (TO_STREAM ? in_arena : in_stream);
+      // lanes past the last vector read 16 bytes that are always there: a predicated load would sit behind a branch
+      x[g] = SC_NT_COPY ? load_global_nt(act[g] ? from : reinterpret_cast<uintptr_t>(&g_nothing))
+                        : load_global_at(act[g] ? from : reinterpret_cast<uintptr_t>(&g_nothing));
+      if (TO_STREAM) {
+        wbyte[g] = (uint32_t)__builtin_amdgcn_ds_bpermute(l4, (int)b);
+        head[g] = act[g] && i == Pl;
+      }
+    }
 #pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const size_t blk = first + 2 * (size_t)u;
-    if (blk >= nblocks) continue;
-    uint8_t *to = dst + o[u] + (TO_STREAM ? blk + 1 : 0);
-    if (TO_STREAM && k == 0) to[-1] = (uint8_t)b[u];
-    if ((uint32_t)k < b[u]) {
-      if (SC_NT_COPY) __builtin_nontemporal_store(x[u], reinterpret_cast<u32x4_u *>(to + 16 * k));
-      else *reinterpret_cast<u32x4_u *>(to + 16 * k) = x[u];
+    for (int g = 0; g < G; ++g) {
+      // the width byte goes out next to the record's first vector: the two share a line
+      if (TO_STREAM && head[g]) dst[to[g] - 1] = (uint8_t)wbyte[g];
+      if (act[g]) {
+        if (SC_NT_COPY) __builtin_nontemporal_store(x[g], reinterpret_cast<u32x4_u *>(dst + to[g]));
+        else *reinterpret_cast<u32x4_u *>(dst + to[g]) = x[g];
+      }
     }
   }
+  // zero-width blocks have no vector to travel with (behind the payload: loads and stores share one in-order
+  // counter, so a store issued up front would make the first wait for a load wait for its acknowledgement too)
+  if (TO_STREAM && have && b == 0) dst[o + blk] = 0;
 }
 
 hipError_t launch_stream_build(const void *arena, const uint64_t *off, const uint8_t *bits, size_t nblocks, uint8_t *stream,
                                hipStream_t st) {
   if (nblocks == 0) return hipSuccess;
-  constexpr size_t per_wg = 8 * COPY_U;
+  constexpr size_t per_wg = 4 * COPY_WAVE_BLOCKS;
   hipLaunchKernelGGL(k_stream_copy<true>, dim3((unsigned)((nblocks + per_wg - 1) / per_wg)), dim3(256), 0, st,
                      static_cast<const uint8_t *>(arena), stream, off, bits, nblocks);
   return hipGetLastError();
@@ -291,7 +345,7 @@ hipError_t launch_stream_build(const void *arena, const uint64_t *off, const uin
 hipError_t launch_stream_unbuild(const uint8_t *stream, const uint64_t *off, const uint8_t *bits, size_t nblocks, void *arena,
                                  hipStream_t st) {
   if (nblocks == 0) return hipSuccess;
-  constexpr size_t per_wg = 8 * COPY_U;
+  constexpr size_t per_wg = 4 * COPY_WAVE_BLOCKS;
   hipLaunchKernelGGL(k_stream_copy<false>, dim3((unsigned)((nblocks + per_wg - 1) / per_wg)), dim3(256), 0, st, stream,
                      static_cast<uint8_t *>(arena), off, bits, nblocks);
   return hipGetLastError();

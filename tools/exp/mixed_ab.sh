@@ -11,5 +11,5 @@ import sys, json
 for line in sys.stdin:
     tag, body = line.split(' ', 1)
     d = json.loads(body)
-    print(tag, {k: v['ms'] for k, v in d.items() if isinstance(v, dict) and k in ('unpack_mixed', 'pack_mixed', 'unpack_stream', 'stream_decode', 'stream_decode_plain', 'chain_offsets')})"
+    print(tag, {k: v['ms'] for k, v in d.items() if isinstance(v, dict) and k in ('unpack_mixed', 'pack_mixed', 'pack_stream', 'stream_compress', 'unpack_stream', 'stream_decode', 'stream_decode_plain', 'chain_offsets')})"
 done
