@@ -543,3 +543,38 @@ def test_index_respects_max_blocks(dev, orc):
             assert (off[:guard] == -7).all() and (off[guard + cap:] == -7).all(), (target, cap)
             assert np.array_equal(bits[guard:guard + cap].cpu().numpy(), widths[:cap]), (target, cap)
             assert np.array_equal(off[guard:guard + cap].cpu().numpy(), (pos - np.arange(n))[:cap]), (target, cap)
+
+
+@pytest.mark.parametrize("pattern", ["all32", "all0", "alternate", "ramp", "one_wide_among_empty"])
+@pytest.mark.parametrize("nblk", [1, 63, 64, 65, 255, 256, 257, 1000])
+def test_stream_copy_width_extremes(dev, pattern, nblk):
+    """Arena <-> stream copies where a wave's 64 blocks hold anything from no payload vector to 2048 of them, with
+    block counts around the wave and workgroup sizes; checked against the stream laid out in numpy, with guard bytes
+    on both sides of both buffers."""
+    import torch
+
+    k = np.arange(nblk)
+    widths = {"all32": np.full(nblk, 32), "all0": np.zeros(nblk, dtype=np.int64), "alternate": (k % 2) * 32, "ramp": k % 33,
+              "one_wide_among_empty": np.where(k % 64 == 37, 32, 0)}[pattern].astype(np.uint8)
+    off = np.concatenate([[0], np.cumsum(16 * widths.astype(np.uint64))]).astype(np.uint64)
+    nbytes = int(off[-1])
+    rng = np.random.default_rng(nblk * 7 + len(pattern))
+    arena = rng.integers(0, 256, nbytes + 16, dtype=np.uint8)
+    want = np.empty(nbytes + nblk, dtype=np.uint8)
+    for i in range(nblk):
+        p = int(off[i]) + i
+        want[p] = widths[i]
+        want[p + 1:p + 1 + 16 * int(widths[i])] = arena[int(off[i]):int(off[i]) + 16 * int(widths[i])]
+    d_bits, d_off, d_arena = to_dev(widths), to_dev(off[:nblk]), to_dev(arena)
+    for shift in (0, 1, 7):
+        buf = torch.full((want.size + 32,), 0xEE, dtype=torch.uint8, device="cuda")
+        view = buf[8 + shift:8 + shift + want.size]
+        dev.stream_build(d_arena, d_bits, d_off, nbytes, out=view)
+        got = buf.cpu().numpy()
+        assert np.array_equal(got[8 + shift:8 + shift + want.size], want)
+        assert (got[:8 + shift] == 0xEE).all() and (got[8 + shift + want.size:] == 0xEE).all(), "wrote outside the stream"
+        back = torch.full((nbytes + 48,), 0xCC, dtype=torch.uint8, device="cuda")
+        dev.stream_unbuild(view, d_bits, d_off, nbytes, out=back[16:])
+        got = back.cpu().numpy()
+        assert np.array_equal(got[16:16 + nbytes], arena[:nbytes])
+        assert (got[:16] == 0xCC).all() and (got[16 + nbytes:] == 0xCC).all(), "wrote outside the arena"
