@@ -28,37 +28,52 @@ namespace sc {
 // ---------------------------------------------------------------------------
 // chained seeds
 // ---------------------------------------------------------------------------
-// sums[k] = sum of the 128 b-bit fields of block k (its deltas), or, for a
-// 32-bit block, its last raw value.  One block per half-wave, same extraction
-// as the decoder (wave-private LDS slot, funnel shift); nothing is stored but
-// one word per block, so a wave takes U blocks per half with all loads issued
-// up front to have enough bytes in flight.  Lanes past a payload's end re-read
-// its last vector; a zero-width block reads the first 16 bytes of `sums`.
+// sums[k] = sum of the 128 b-bit fields of block k (its deltas) modulo 2^32, or,
+// for a 32-bit block, its last raw value.  One block per half-wave, rows
+// fetched as in the decoder (wave-private LDS slot, funnel shift); nothing is
+// stored but one word per block, so a wave takes U blocks per half with all
+// loads issued up front to have enough bytes in flight.
+//
+// The fields are never isolated.  Let W_k be the 32 bits of a lane's bit stream
+// that start at bit k*b (what the funnel shift delivers; zeros past the stream's
+// end).  Then W_k = f_k + 2^b * W_{k+1} (mod 2^32), so with T = W_0 + ... + W_31
+//     f_0 + ... + f_31 = T - 2^b * (T - W_0)   (mod 2^32),
+// and the same holds for the sum over the block's four lane streams: no mask per
+// value.  Lanes past a payload's end load 16 zero bytes.
+//
+// (Measured with it: 326 -> 224 vector instructions per wave, 6 % faster on the aligned arena, no change on the byte
+// stream, where every payload load is unaligned.  Workgroups that touch widths and offsets ahead of the others, as
+// in the per-block-width decoder, change nothing either way.)
 #ifndef SC_SUMS_U
 #define SC_SUMS_U 8
 #endif
 constexpr int SUMS_U = SC_SUMS_U;
+constexpr size_t SUMS_PER_WG = 8 * SUMS_U;
 
 __global__ __launch_bounds__(256) void k_block_sums(const uint8_t *payload, const uint64_t *off, const uint8_t *bits,
                                                     size_t nblocks, uint32_t stream_layout, uint32_t *sums) {
   __shared__ u32x4 lds[4][2][33];
-  __shared__ uint32_t gathered[4][2 * SUMS_U];
+  __shared__ uint32_t gathered[4][2][2 * SUMS_U];  // [wave][0: W_0 over the four lane streams, 1: T or last value][block]
   constexpr int U = SUMS_U;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int h = lane >> 5, k = lane & 31;
+  const size_t tile = blockIdx.x;
   u32x4 *slot = lds[wv][h];
   uint32_t b[U], o[U];
   u32x4 ld[U];
   uintptr_t first_payload;
+  uint32_t mb;
   // widths and offsets of the wave's 2 * U consecutive blocks: one coalesced load per array (blocks past the end
-  // repeat the last one), handed to the half-waves through the LDS crossbar: this kernel is bound by vector-ALU
-  // work, and a ds_bpermute costs it one instruction where the scalar hand-out of the decoders costs four.  The
-  // offsets travel as 32-bit distances from the wave's first block (16 blocks span at most 8 KiB)
+  // repeat the last one), handed to the half-waves through the LDS crossbar (a ds_bpermute costs one instruction
+  // where the scalar hand-out of the decoders costs four).  The offsets travel as 32-bit distances from the wave's
+  // first block (16 blocks span at most 8 KiB)
   constexpr int NB = 2 * U;
-  const size_t wb = ((size_t)blockIdx.x * 4 + wv) * NB;
+  const size_t wb = (tile * 4 + wv) * NB;
+  if (wb >= nblocks) return;  // (whole waves; no workgroup barrier below)
   {
     const size_t mine = wb + (size_t)(lane % NB) < nblocks ? wb + (size_t)(lane % NB) : nblocks - 1;
-    const uint32_t mb = bits[mine];
+    mb = bits[mine];
+    mb = mb > 32 ? 32 : mb;
     const uint64_t mo = off[mine] + (stream_layout ? mine + 1 : 0);
     const uint64_t mo0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(mo >> 32)) << 32) |
                          (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)mo);
@@ -71,34 +86,29 @@ __global__ __launch_bounds__(256) void k_block_sums(const uint8_t *payload, cons
       o[u] = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)rel);
     }
   }
+  const uintptr_t zeros = reinterpret_cast<uintptr_t>(&g_nothing);
 #pragma unroll
-  for (int u = 0; u < U; ++u) {
-    b[u] = b[u] > 32 ? 32 : b[u];
-    const uint32_t last = b[u] ? b[u] - 1 : 0;
-    uintptr_t at = first_payload + (o[u] + 16 * ((uint32_t)k < last ? (uint32_t)k : last));
-    at = (uint32_t)k > last ? (at & ~(uintptr_t)15) : at;  // idle lanes: an aligned address coalesces better
-    ld[u] = load_global_at(b[u] ? at : reinterpret_cast<uintptr_t>(sums));
-  }
+  for (int u = 0; u < U; ++u)
+    ld[u] = load_global_at((uint32_t)k < b[u] ? first_payload + (o[u] + 16 * (uint32_t)k) : zeros);
+  const bool edge = k == 0 || k == 31;
+  uint32_t *mine_out = &gathered[wv][k & 1][h];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     wave_lds_fence();
     slot[k] = ld[u];
     wave_lds_fence();
     const uint32_t p = (uint32_t)k * b[u], w = p >> 5, s = p & 31;
-    const u32x4 lo = slot[w], hi = slot[w + 1];
-    const uint32_t m = field_mask(b[u]);
-    u32x4 v;
-    v.x = funnel(hi.x, lo.x, s) & m;
-    v.y = funnel(hi.y, lo.y, s) & m;
-    v.z = funnel(hi.z, lo.z, s) & m;
-    v.w = funnel(hi.w, lo.w, s) & m;
-    const uint32_t total = half_scan_add(v.x + v.y + v.z + v.w);  // lane 31 of the half-wave: the block's sum
-    const uint32_t res = b[u] == 32 ? v.w : total;
-    // the last lane of each half-wave leaves the result in LDS, for one coalesced store at the end
-    if (k == 31) gathered[wv][2 * u + h] = res;
+    const u32x4 lo = slot[w], hi = slot[w + 1];  // b = 32: s = 0, hi (slot[32] for the last row) is not used
+    const uint32_t x = funnel(hi.x, lo.x, s), y = funnel(hi.y, lo.y, s), z = funnel(hi.z, lo.z, s), q = funnel(hi.w, lo.w, s);
+    const uint32_t total = half_scan_add(x + y + z + q);  // lane 0 of the half-wave: W_0 (s = 0, w = 0), lane 31: T
+    // the first and the last lane of each half-wave leave their results in LDS, for one coalesced store at the end
+    if (edge) mine_out[2 * u] = b[u] == 32 ? q : total;
   }
   wave_lds_fence();
-  if (lane < NB && wb + (size_t)lane < nblocks) sums[wb + (size_t)lane] = gathered[wv][lane];
+  if (lane < NB && wb + (size_t)lane < nblocks) {
+    const uint32_t w0 = gathered[wv][0][lane], t = gathered[wv][1][lane];
+    sums[wb + (size_t)lane] = mb >= 32 ? t : t - ((t - w0) << mb);
+  }
 }
 
 // (restart flag << 32) | value
@@ -216,8 +226,8 @@ hipError_t launch_chain_offsets(uint32_t init, const void *payload, const uint64
   uint32_t *sums = reinterpret_cast<uint32_t *>(ws);
   uint64_t *tile_sum = reinterpret_cast<uint64_t *>(ws + align256(4 * nblocks));
   uint32_t *tile_in = reinterpret_cast<uint32_t *>(ws + align256(4 * nblocks) + align256(8 * ntiles));
-  constexpr size_t per_wg = 8 * SUMS_U;
-  hipLaunchKernelGGL(k_block_sums, dim3((unsigned)((nblocks + per_wg - 1) / per_wg)), dim3(256), 0, st,
+  const size_t nwg = (nblocks + SUMS_PER_WG - 1) / SUMS_PER_WG;
+  hipLaunchKernelGGL(k_block_sums, dim3((unsigned)nwg), dim3(256), 0, st,
                      static_cast<const uint8_t *>(payload), off, bits, nblocks, stream_layout ? 1u : 0u, sums);
   hipLaunchKernelGGL(k_chain_tiles, dim3((unsigned)ntiles), dim3(256), 0, st, bits, sums, nblocks, tile_sum);
   hipLaunchKernelGGL(k_chain_spine, dim3(1), dim3(256), 0, st, tile_sum, ntiles, init, tile_in);

@@ -110,6 +110,8 @@ def stream(n, nblk, reps):
         "stream_unbuild": (lambda: L.simdcomp_hip_stream_unbuild(P(strm), P(off), P(bits), nblk, P(arena2), st), 2 * T + 10 * nblk),
         "chain_offsets": (lambda: L.simdcomp_hip_chain_offsets(0, P(strm), P(off), P(bits), nblk, 1, P(chained), P(ws_c), st),
                           T + 14 * nblk),
+        "chain_offsets_arena": (lambda: L.simdcomp_hip_chain_offsets(0, P(arena), P(off), P(bits), nblk, 0, P(chained), P(ws_c), st),
+                                T + 13 * nblk),
         "unpack_stream": (lambda: codec.unpack_stream(1, strm, bits, off, nblk, initvalues=seeds, out=out), 512 * nblk + T + 14 * nblk),
         "unpack_mixed": (lambda: codec.unpack_mixed(1, arena, bits, off, nblk, initvalues=seeds, out=out), 512 * nblk + T + 13 * nblk),
         "pack_stream": (lambda: codec.pack_stream(1, ids, bits, off, strm2, initvalue=0), 512 * nblk + T + 10 * nblk),
