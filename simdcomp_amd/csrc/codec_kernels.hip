@@ -447,6 +447,10 @@ __device__ __forceinline__ void touch_bytes(const void *base, size_t byte0, size
 #ifndef SC_NT_PAYLOAD_MINB
 #define SC_NT_PAYLOAD_MINB 20
 #endif
+// (not for the 16-lane layout, whose payload vectors of one block lie 64 bytes apart: 71-72 -> 73 % at 24 and 32 bits)
+#ifndef SC_NT_PAYLOAD_MAXLS
+#define SC_NT_PAYLOAD_MAXLS 2
+#endif
 #ifndef SC_NT_MIXED_UNPACK
 #define SC_NT_MIXED_UNPACK 0
 #endif
@@ -540,7 +544,7 @@ __global__ __launch_bounds__(BS) void k_unpack_fast(UnpackArgs a, uint32_t nwg =
     if constexpr (B != 0) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        if constexpr (B >= SC_NT_PAYLOAD_MINB || (B < 0 && SC_NT_MIXED_UNPACK)) ld[u] = __builtin_nontemporal_load(reinterpret_cast<const __attribute__((address_space(1))) u32x4_u *>(reinterpret_cast<uintptr_t>(src[u])));
+        if constexpr ((B >= SC_NT_PAYLOAD_MINB && LS < SC_NT_PAYLOAD_MAXLS) || (B < 0 && SC_NT_MIXED_UNPACK)) ld[u] = __builtin_nontemporal_load(reinterpret_cast<const __attribute__((address_space(1))) u32x4_u *>(reinterpret_cast<uintptr_t>(src[u])));
         else ld[u] = load_global_at(reinterpret_cast<uintptr_t>(src[u]));
       }
     }
@@ -597,6 +601,12 @@ __global__ __launch_bounds__(BS) void k_unpack_fast(UnpackArgs a, uint32_t nwg =
 #ifndef SC_NT_PACKIN_MINB
 #define SC_NT_PACKIN_MINB 1
 #endif
+// The 16-lane layout (LS = 2) reads every 64-byte line of its input with two instructions (32 bytes each): a
+// non-temporal first read would make the second one fetch the line again (63-71 % of HBM peak against 73-78 % with
+// ordinary loads); its payload stores stay non-temporal up to 8 bits only (b = 16..32: 64-70 % against 72-76 %).
+#ifndef SC_NT_PACK_LS2_MAXB
+#define SC_NT_PACK_LS2_MAXB 8
+#endif
 #ifndef SC_NT_MIXED
 #define SC_NT_MIXED 1
 #endif
@@ -620,7 +630,7 @@ __global__ __launch_bounds__(BS) void k_pack_fast(PackArgs a) {
       const size_t blk = first + 2 * (size_t)u;
       {
         const u32x4 *row = reinterpret_cast<const u32x4 *>(a.in + (((blk >> LS) * 128) << LS) + 4 * (blk & ((1u << LS) - 1)) + ((4 * (size_t)k) << LS));
-        if constexpr (B >= SC_NT_PACKIN_MINB || (B < 0 && SC_NT_MIXED)) x[u] = __builtin_nontemporal_load(row);
+        if constexpr ((B >= SC_NT_PACKIN_MINB && LS < 2) || (B < 0 && SC_NT_MIXED)) x[u] = __builtin_nontemporal_load(row);
         else x[u] = stream_load(row);
       }
       if constexpr (B >= 0) {
@@ -751,11 +761,11 @@ __global__ __launch_bounds__(BS) void k_pack_fast(PackArgs a) {
       const uint32_t bu = b[u];
       const uint32_t w = ((uint32_t)k * bu) >> 5;
       if constexpr (B == 32) {
-        if constexpr (B >= SC_NT_PACK_MINB) __builtin_nontemporal_store(x[u], reinterpret_cast<u32x4 *>(pbase[u] + ((16 * k) << LS)));
+        if constexpr (B >= SC_NT_PACK_MINB && (LS < 2 || B <= SC_NT_PACK_LS2_MAXB)) __builtin_nontemporal_store(x[u], reinterpret_cast<u32x4 *>(pbase[u] + ((16 * k) << LS)));
         else *reinterpret_cast<u32x4 *>(pbase[u] + ((16 * k) << LS)) = x[u];
       } else if constexpr (B > 0) {
         const bool last = (k == 31) || ((((uint32_t)(k + 1) * bu) >> 5) != w);
-        if constexpr (B >= SC_NT_PACK_MINB) {
+        if constexpr (B >= SC_NT_PACK_MINB && (LS < 2 || B <= SC_NT_PACK_LS2_MAXB)) {
           if (last) __builtin_nontemporal_store(acc[u], reinterpret_cast<u32x4 *>(pbase[u] + ((16 * w) << LS)));
         } else {
           if (last) *reinterpret_cast<u32x4 *>(pbase[u] + ((16 * w) << LS)) = acc[u];
