@@ -65,6 +65,10 @@ struct Staging {
   // Small operands skip the copies: two host buffers that the GPU maps; the kernels read and write them in place
   // over PCIe and the call costs one launch and one synchronisation instead of two copies on top of those.
   uint8_t *zin = nullptr, *zout = nullptr;
+  // Completion of a small call: the stream writes a sequence number into a word of mapped host memory behind the
+  // kernel, and the calling thread polls that word instead of going through hipStreamSynchronize.
+  uint32_t *done_word = nullptr;
+  uint32_t done_seq = 0;
 
   // with `device` current
   void create(int dev) {
@@ -73,6 +77,33 @@ struct Staging {
     ck(hipMalloc(reinterpret_cast<void **>(&result4), 64), "hipMalloc");
     ck(hipHostMalloc(reinterpret_cast<void **>(&zin), ZC_BYTES + 128, hipHostMallocMapped | hipHostMallocCoherent), "hipHostMalloc");
     ck(hipHostMalloc(reinterpret_cast<void **>(&zout), ZC_BYTES + 128, hipHostMallocMapped | hipHostMallocCoherent), "hipHostMalloc");
+    ck(hipHostMalloc(reinterpret_cast<void **>(&done_word), 64, hipHostMallocMapped | hipHostMallocCoherent), "hipHostMalloc");
+    *done_word = 0;
+  }
+
+  // Wait until everything enqueued on `st` so far has finished and its writes to the mapped buffers are visible.
+  void finish(hipStream_t st) {
+    static const bool poll = [] {
+      const char *e = getenv("SIMDCOMP_HIP_POLL");
+      return !(e && e[0] == '0');
+    }();
+    if (poll) {
+      const uint32_t want = ++done_seq;
+      if (hipStreamWriteValue32(st, done_word, want, 0) == hipSuccess) {
+        // bounded: a stream that never gets there (a fault on the device) is reported by the synchronisation below
+        for (uint32_t spins = 0; spins < (1u << 22); ++spins) {
+          if (__atomic_load_n(done_word, __ATOMIC_ACQUIRE) == want) {
+            // every so often through the runtime as well, so that it retires the commands it keeps track of
+            if ((want & 1023u) == 0) ck(hipStreamSynchronize(st), "hipStreamSynchronize");
+            return;
+          }
+          __builtin_ia32_pause();
+        }
+      } else {
+        (void)hipGetLastError();
+      }
+    }
+    ck(hipStreamSynchronize(st), "hipStreamSynchronize");
   }
 
   void reserve(int slot, size_t in_bytes, size_t out_bytes) {
@@ -208,7 +239,7 @@ void block_pack(int mode, bool masked, uint32_t initvalue, const uint32_t *in, v
   a.seed0 = initvalue;  // seeds == nullptr: block 0 of a chained d1 stream / uniform frame base
   a.lane_groups = groups;
   ck(sc::launch_pack(mode, masked, false, a, st), "pack launch");
-  ck(hipStreamSynchronize(st), "hipStreamSynchronize");
+  s.finish(st);
   memcpy(out, s.zout, 16 * (size_t)bit * groups);
 }
 
@@ -227,7 +258,7 @@ void block_unpack(int mode, uint32_t initvalue, const void *in, uint32_t *out, u
   a.seed0 = initvalue;
   a.lane_groups = groups;
   ck(sc::launch_unpack(mode, false, a, st), "unpack launch");
-  ck(hipStreamSynchronize(st), "hipStreamSynchronize");
+  s.finish(st);
   memcpy(out, s.zout, 512 * (size_t)groups);
 }
 
@@ -284,7 +315,7 @@ void *pack_length_host(int kind, uint32_t initvalue, const uint32_t *in, size_t 
     const uint32_t *z_in = reinterpret_cast<const uint32_t *>(s.zi());
     if (kind == 0) ckapi(simdcomp_hip_pack_length(z_in, length, s.zout, bit, st), "pack_length");
     else ckapi(simdcomp_hip_packFOR_length(initvalue, z_in, length, s.zout, bit, 0, st), "packFOR_length");
-    ck(hipStreamSynchronize(st), "hipStreamSynchronize");
+    s.finish(st);
     memcpy(o, s.zout, nbytes);
     return o + nbytes;
   }
@@ -323,7 +354,7 @@ const void *unpack_length_host(int kind, uint32_t initvalue, const void *in, siz
     uint32_t *z_out = reinterpret_cast<uint32_t *>(s.zout);
     if (kind == 0) ckapi(simdcomp_hip_unpack_length(s.zi(), length, z_out, bit, st), "unpack_length");
     else ckapi(simdcomp_hip_unpackFOR_length(initvalue, s.zi(), length, z_out, bit, st), "unpackFOR_length");
-    ck(hipStreamSynchronize(st), "hipStreamSynchronize");
+    s.finish(st);
     memcpy(out, z_out, length * 4);
     return p + nbytes;
   }
