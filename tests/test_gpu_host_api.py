@@ -259,3 +259,44 @@ def test_host_api_follows_the_callers_current_device(lib, orc):
     lib.simdpack(p(x), p(buf), 9)
     assert np.array_equal(buf, orc.simdpack(x, 9))
     assert torch.cuda.current_device() == before
+
+
+def test_small_calls_with_and_without_polled_completion():
+    """Small calls wait for a word the stream writes behind the kernel; SIMDCOMP_HIP_POLL=0 goes through
+    hipStreamSynchronize instead.  Both give the reference's bytes (a fresh process each: the switch is read once)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = r"""
+import sys, ctypes as C, numpy as np
+sys.path.insert(0, %r)
+import oracle
+from simdcomp_amd import binding
+L = binding.lib()
+vp = C.c_void_p
+L.simdpackwithoutmaskd1.argtypes = [C.c_uint32, vp, vp, C.c_uint32]; L.simdpackwithoutmaskd1.restype = None
+L.simdunpackd1.argtypes = [C.c_uint32, vp, vp, C.c_uint32]; L.simdunpackd1.restype = None
+L.simdpack_length.argtypes = [vp, C.c_size_t, vp, C.c_uint32]; L.simdpack_length.restype = vp
+rng = np.random.default_rng(5)
+orc = oracle.Oracle()
+for it in range(300):
+    b = int(rng.integers(0, 33))
+    x = np.cumsum(rng.integers(0, 1 << min(b, 24), 128, dtype=np.uint64)).astype(np.uint32)
+    out = np.zeros(4 * max(b, 1), np.uint32); back = np.zeros(128, np.uint32)
+    L.simdpackwithoutmaskd1(0, x.ctypes.data, out.ctypes.data, b)
+    assert np.array_equal(out.view(np.uint8)[:16 * b], orc.simdpackwithoutmaskd1(0, x, b)), (it, b)
+    L.simdunpackd1(0, out.ctypes.data, back.ctypes.data, b)
+    assert np.array_equal(back, orc.simdunpackd1(0, out, b)) and np.array_equal(back, x), (it, b)
+n = 1000
+y = rng.integers(0, 1 << 11, n, dtype=np.uint32)
+buf = np.zeros(n + 64, np.uint32)
+end = L.simdpack_length(y.ctypes.data, n, buf.ctypes.data, 11)
+assert end - buf.ctypes.data == orc.compressedbytes(n, 11)
+print("ok")
+""" % root
+    for poll in ("1", "0"):
+        env = dict(os.environ, SIMDCOMP_HIP_POLL=poll)
+        out = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=300, env=env)
+        assert out.returncode == 0 and out.stdout.strip().endswith("ok"), (poll, out.stdout[-500:], out.stderr[-2000:])
