@@ -1200,11 +1200,16 @@ constexpr bool pack_narrow_shape(int b) { return (b > 0 && b <= 12) || b == 16; 
 constexpr int pack_threads(int b) { return (b >= SC_PW_LO && b <= SC_PW_HI) ? SC_PW_BS : (b < 0 ? SC_PM_BS : (pack_narrow_shape(b) ? (b >= 4 ? SC_PN_BS : 128) : 256)); }
 constexpr int pack_steps(int b) { return (b >= SC_PW_LO && b <= SC_PW_HI) ? SC_PW_U : (b < 0 ? SC_PM_U : (pack_narrow_shape(b) ? (b >= 4 ? SC_PN_U : 2) : 1)); }
 
+// (16-lane layout: 128 threads at every width; 256 from 20 bits on, as the 4-lane layout has them, ran at 72.5 %
+// against 75-76 % at 24 and 32 bits)
+#ifndef SC_U16_BS
+#define SC_U16_BS 128
+#endif
 // index 0 is the per-block-width instance (B = -1), index 1 + b the uniform width b
 template <int MODE, int BP1, int LS = 0>
 static size_t launch_unpack_fast(const UnpackArgs &a, hipStream_t st) {
   // 16-lane layout: two steps, so that a wave's four blocks are the four groups of one wide block
-  constexpr int U = LS == 2 ? 2 : unpack_steps(BP1 - 1), BS = unpack_threads(BP1 - 1), PF = unpack_prefetch_group(BP1 - 1);
+  constexpr int U = LS == 2 ? 2 : unpack_steps(BP1 - 1), BS = (LS == 2 && SC_U16_BS) ? SC_U16_BS : unpack_threads(BP1 - 1), PF = unpack_prefetch_group(BP1 - 1);
   constexpr size_t per_wg = (size_t)(BS / 32) * U;
   const size_t nwg = a.nblocks / per_wg;
   if (nwg == 0) return 0;
