@@ -819,7 +819,7 @@ __global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
     u32x4 x[U];
     uint32_t seed[U];
     bool valid[U];
-    uint32_t out_bits = 0, out_seed = 0;
+    uint32_t out_bits = 0, out_seed = 0, out_min = 0, out_max = 0;
     // every load is issued unconditionally (a block past the end re-reads the last one; only the stores are
     // predicated), and the U loads of a kind back to back: behind a per-step branch they would wait for one another
     size_t bc[U];
@@ -866,21 +866,25 @@ __global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const size_t blk = first + 2 * (size_t)u;
       if constexpr (WHAT == RED_MINMAX) {
         uint32_t lo = min(min(x[u].x, x[u].y), min(x[u].z, x[u].w));
         uint32_t hi = max(max(x[u].x, x[u].y), max(x[u].z, x[u].w));
-        // butterfly over the 32 lanes of the half-wave
-#pragma unroll
-        for (int d = 1; d < 32; d <<= 1) {
-          lo = min(lo, (uint32_t)__shfl_xor((int)lo, d, 32));
-          hi = max(hi, (uint32_t)__shfl_xor((int)hi, d, 32));
-        }
-        if (valid[u] && k == 0) {
-          if (a.min_out) a.min_out[blk] = lo;
-          if (a.max_out) a.max_out[blk] = hi;
-          if (a.bits_out) a.bits_out[blk] = (uint8_t)bits_of(hi - lo);
-        }
+        // min / max into lane 31 of the half-wave (a lane with no source keeps its own value), then gathered like
+        // the widths below: one store per array and wave instead of one per block
+        lo = min(lo, dpp_keep<DPP_ROW_SHR1>(lo));
+        hi = max(hi, dpp_keep<DPP_ROW_SHR1>(hi));
+        lo = min(lo, dpp_keep<DPP_ROW_SHR2>(lo));
+        hi = max(hi, dpp_keep<DPP_ROW_SHR2>(hi));
+        lo = min(lo, dpp_keep<DPP_ROW_SHR4>(lo));
+        hi = max(hi, dpp_keep<DPP_ROW_SHR4>(hi));
+        lo = min(lo, dpp_keep<DPP_ROW_SHR8>(lo));
+        hi = max(hi, dpp_keep<DPP_ROW_SHR8>(hi));
+        lo = min(lo, dpp_keep<DPP_ROW_BCAST15, 0xA>(lo));
+        hi = max(hi, dpp_keep<DPP_ROW_BCAST15, 0xA>(hi));
+        const uint32_t lo0 = (uint32_t)__builtin_amdgcn_readlane((int)lo, 31), lo1 = (uint32_t)__builtin_amdgcn_readlane((int)lo, 63);
+        const uint32_t hi0 = (uint32_t)__builtin_amdgcn_readlane((int)hi, 31), hi1 = (uint32_t)__builtin_amdgcn_readlane((int)hi, 63);
+        out_min = lane == 2 * u ? lo0 : (lane == 2 * u + 1 ? lo1 : out_min);
+        out_max = lane == 2 * u ? hi0 : (lane == 2 * u + 1 ? hi1 : out_max);
       } else {
         u32x4 v = x[u];
         if constexpr (WHAT == RED_MAXBITSD1) {
@@ -906,11 +910,17 @@ __global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
         }
       }
     }
-    if constexpr (WHAT != RED_MINMAX) {
+    {
       const size_t mine = tile * per_iter + (size_t)wv * 2 * U + (size_t)lane;
       if (lane < 2 * U && mine < a.nblocks) {
-        a.bits_out[mine] = (uint8_t)out_bits;
-        if (WHAT == RED_MAXBITSD1 && a.seeds_out) a.seeds_out[mine] = out_seed;
+        if constexpr (WHAT == RED_MINMAX) {
+          if (a.min_out) a.min_out[mine] = out_min;
+          if (a.max_out) a.max_out[mine] = out_max;
+          if (a.bits_out) a.bits_out[mine] = (uint8_t)bits_of(out_max - out_min);
+        } else {
+          a.bits_out[mine] = (uint8_t)out_bits;
+          if (WHAT == RED_MAXBITSD1 && a.seeds_out) a.seeds_out[mine] = out_seed;
+        }
       }
     }
   }
@@ -1054,27 +1064,12 @@ __global__ void k_reduce_array_init(uint32_t *r) {
   r[3] = 0;
 }
 
-__global__ __launch_bounds__(256) void k_reduce_array(const uint32_t *in, size_t n, uint32_t init, uint32_t *r) {
-  uint32_t o = 0, od = 0, lo = 0xFFFFFFFFu, hi = 0;
-  const size_t stride = (size_t)gridDim.x * 256, gid = (size_t)blockIdx.x * 256 + threadIdx.x;
-  const bool vec = (reinterpret_cast<uintptr_t>(in) & 15u) == 0;
-  const size_t nvec = vec ? n / 4 : 0;
-  const u32x4 *in4 = reinterpret_cast<const u32x4 *>(in);
-  for (size_t j = gid; j < nvec; j += stride) {
-    const u32x4 v = in4[j];
-    const uint32_t prev = j ? in[4 * j - 1] : init;
-    o |= v.x | v.y | v.z | v.w;
-    od |= (v.x - prev) | (v.y - v.x) | (v.z - v.y) | (v.w - v.z);
-    lo = min(lo, min(min(v.x, v.y), min(v.z, v.w)));
-    hi = max(hi, max(max(v.x, v.y), max(v.z, v.w)));
-  }
-  for (size_t i = 4 * nvec + gid; i < n; i += stride) {
-    const uint32_t v = in[i], prev = i ? in[i - 1] : init;
-    o |= v;
-    od |= v - prev;
-    lo = min(lo, v);
-    hi = max(hi, v);
-  }
+// What a workgroup's lanes hold goes into the four results: butterflies inside the waves, the waves combined through
+// LDS, then at most one atomic per result and workgroup -- none where the result already covers the workgroup's
+// share (results only ever gain bits / move outwards, so a stale look at them can cost an atomic, never lose one):
+// half a million workgroups hammering four words with atomics would take longer than reading the array.
+__device__ __forceinline__ void reduce_array_commit(uint32_t o, uint32_t od, uint32_t lo, uint32_t hi, uint32_t *r) {
+  __shared__ uint32_t part[4][4];
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) {
     o |= (uint32_t)__shfl_xor((int)o, d, 64);
@@ -1082,12 +1077,84 @@ __global__ __launch_bounds__(256) void k_reduce_array(const uint32_t *in, size_t
     lo = min(lo, (uint32_t)__shfl_xor((int)lo, d, 64));
     hi = max(hi, (uint32_t)__shfl_xor((int)hi, d, 64));
   }
+  const int wv = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) {
-    if (o) atomicOr(&r[0], o);
-    if (od) atomicOr(&r[1], od);
-    atomicMin(&r[2], lo);
-    atomicMax(&r[3], hi);
+    part[wv][0] = o;
+    part[wv][1] = od;
+    part[wv][2] = lo;
+    part[wv][3] = hi;
   }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    o = part[0][0] | part[1][0] | part[2][0] | part[3][0];
+    od = part[0][1] | part[1][1] | part[2][1] | part[3][1];
+    lo = min(min(part[0][2], part[1][2]), min(part[2][2], part[3][2]));
+    hi = max(max(part[0][3], part[1][3]), max(part[2][3], part[3][3]));
+    const uint32_t c0 = __hip_atomic_load(&r[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t c1 = __hip_atomic_load(&r[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t c2 = __hip_atomic_load(&r[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t c3 = __hip_atomic_load(&r[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (o & ~c0) atomicOr(&r[0], o);
+    if (od & ~c1) atomicOr(&r[1], od);
+    if (lo < c2) atomicMin(&r[2], lo);
+    if (hi > c3) atomicMax(&r[3], hi);
+  }
+}
+
+// The bulk of a 16-byte aligned array: a workgroup takes REDUCE_ARRAY_U * 4 KiB and ends (one-shot workgroups, all
+// loads of a wave issued together, non-temporal: see the block kernels); a lane's predecessor is the last value of
+// the lane below (DPP), of the wave's previous step (lane 63), or, for the wave's first vector, one word from memory.
+constexpr int REDUCE_ARRAY_U = 8;
+
+__global__ __launch_bounds__(256) void k_reduce_array_bulk(const uint32_t *in, uint32_t init, uint32_t *r) {
+  constexpr int U = REDUCE_ARRAY_U;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  // wave w of workgroup g: vectors [(g * 4 + w) * U * 64, + U * 64), step u the 64 consecutive ones from u * 64 on
+  const size_t v0 = ((size_t)blockIdx.x * 4 + wv) * U * 64;
+  const u32x4 *in4 = reinterpret_cast<const u32x4 *>(in) + v0;
+  u32x4 x[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) x[u] = reduce_load(in4 + u * 64 + lane);
+  const uint32_t before = v0 ? in[4 * v0 - 1] : init;
+  uint32_t o = 0, od = 0, lo = 0xFFFFFFFFu, hi = 0;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const u32x4 v = x[u];
+    uint32_t prev = dpp0<DPP_WAVE_SHR1>(v.w);
+    const uint32_t first_prev = u ? (uint32_t)__builtin_amdgcn_readlane((int)x[u ? u - 1 : 0].w, 63) : before;
+    prev = lane ? prev : first_prev;
+    o |= v.x | v.y | v.z | v.w;
+    od |= (v.x - prev) | (v.y - v.x) | (v.z - v.y) | (v.w - v.z);
+    lo = min(lo, min(min(v.x, v.y), min(v.z, v.w)));
+    hi = max(hi, max(max(v.x, v.y), max(v.z, v.w)));
+  }
+  reduce_array_commit(o, od, lo, hi, r);
+}
+
+// Everything else: short arrays, the end behind the last whole workgroup of the bulk kernel, arrays that are only
+// 4-byte aligned.  `first` is the index of the first element this launch looks at.
+__global__ __launch_bounds__(256) void k_reduce_array(const uint32_t *in, size_t first, size_t n, uint32_t init, uint32_t *r) {
+  uint32_t o = 0, od = 0, lo = 0xFFFFFFFFu, hi = 0;
+  const size_t stride = (size_t)gridDim.x * 256, gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const bool vec = (reinterpret_cast<uintptr_t>(in) & 15u) == 0 && (first & 3) == 0;
+  const size_t nvec = vec ? n / 4 : first / 4;
+  const u32x4 *in4 = reinterpret_cast<const u32x4 *>(in);
+  for (size_t j = first / 4 + gid; j < nvec; j += stride) {
+    const u32x4 v = in4[j];
+    const uint32_t prev = j ? in[4 * j - 1] : init;
+    o |= v.x | v.y | v.z | v.w;
+    od |= (v.x - prev) | (v.y - v.x) | (v.z - v.y) | (v.w - v.z);
+    lo = min(lo, min(min(v.x, v.y), min(v.z, v.w)));
+    hi = max(hi, max(max(v.x, v.y), max(v.z, v.w)));
+  }
+  for (size_t i = (vec ? 4 * nvec : first) + gid; i < n; i += stride) {
+    const uint32_t v = in[i], prev = i ? in[i - 1] : init;
+    o |= v;
+    od |= v - prev;
+    lo = min(lo, v);
+    hi = max(hi, v);
+  }
+  reduce_array_commit(o, od, lo, hi, r);
 }
 
 // ---------------------------------------------------------------------------
@@ -1457,10 +1524,21 @@ hipError_t launch_checksum(const uint32_t *data, const uint32_t *other, size_t n
 hipError_t launch_reduce_array(const uint32_t *in, size_t length, uint32_t init, uint32_t *result4, hipStream_t st) {
   hipLaunchKernelGGL(k_reduce_array_init, dim3(1), dim3(1), 0, st, result4);
   if (length) {
-    size_t g = (length / 4 + 255) / 256;
-    if (g > 2048) g = 2048;
-    if (g < 1) g = 1;
-    hipLaunchKernelGGL(k_reduce_array, dim3((unsigned)g), dim3(256), 0, st, in, length, init, result4);
+    // whole workgroups of the bulk kernel first (aligned arrays), the generic kernel for what is left
+    constexpr size_t per_wg = (size_t)REDUCE_ARRAY_U * 256 * 4;  // integers
+    size_t first = 0;
+    if ((reinterpret_cast<uintptr_t>(in) & 15u) == 0 && length >= per_wg) {
+      size_t nwg = length / per_wg;
+      if (nwg > ((size_t)1 << 30)) nwg = (size_t)1 << 30;  // (grid limit; the generic kernel takes the rest)
+      hipLaunchKernelGGL(k_reduce_array_bulk, dim3((unsigned)nwg), dim3(256), 0, st, in, init, result4);
+      first = nwg * per_wg;
+    }
+    if (first < length) {
+      size_t g = ((length - first) / 4 + 255) / 256;
+      if (g > 2048) g = 2048;
+      if (g < 1) g = 1;
+      hipLaunchKernelGGL(k_reduce_array, dim3((unsigned)g), dim3(256), 0, st, in, first, length, init, result4);
+    }
   }
   return hipGetLastError();
 }

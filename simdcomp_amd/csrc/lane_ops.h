@@ -62,6 +62,13 @@ __device__ __forceinline__ uint32_t dpp0(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWMASK, 0xF, false);
 }
 
+// The same, but a lane with no source (or in a masked-off row) keeps its own `v`: for reductions under min / max,
+// which have no neutral element that DPP could fill in.
+template <int CTRL, int ROWMASK = 0xF>
+__device__ __forceinline__ uint32_t dpp_keep(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROWMASK, 0xF, false);
+}
+
 __device__ __forceinline__ uint32_t field_mask(uint32_t b) { return (uint32_t)((1ull << b) - 1ull); }
 
 __device__ __forceinline__ uint32_t funnel(uint32_t hi, uint32_t lo, uint32_t s) {

@@ -359,3 +359,33 @@ def test_randomised_shapes(dev, orc, seed):
         else:
             dec = dev.unpack(got, nblk, bit)
         assert np.array_equal(to_np(dec), orc.batch_unpack(mode, want, nblk, bit, seeds=seeds)), (mode, bit, nblk)
+
+
+def test_reduce_length_exact_at_every_boundary(dev):
+    """The whole-array reduction against numpy, exactly (not only the widths of its results): arrays that are one
+    step up at position i have a single non-zero difference, which any wrong predecessor at a lane / step / wave /
+    workgroup / kernel boundary would add bits to; sizes around the bulk kernel's workgroups, aligned and not."""
+    import torch
+
+    rng = np.random.default_rng(77)
+    per_wg = 8192
+    for n in (1, 5, 255, 256, 257, 2047, 2048, 2049, per_wg - 1, per_wg, per_wg + 1, 3 * per_wg + 77, 5 * per_wg):
+        marks = sorted({0, 1, 3, 4, 255, 256, 257, 2047, 2048, per_wg - 1, per_wg, per_wg + 1, 2 * per_wg, n - 1, n // 2})
+        for i in [m for m in marks if m < n]:
+            c, step = 1000 + i, 1 << int(rng.integers(0, 31))
+            x = np.full(n + 8, c, dtype=np.uint32)
+            x[i:] = (c + step) & 0xFFFFFFFF
+            for shift in (0, 1):  # 16-byte aligned, and only 4-byte aligned
+                buf = torch.from_numpy(np.concatenate([np.zeros(shift, np.uint32), x]).view(np.int32)).cuda()
+                got = to_np(dev.reduce_length(buf[shift:], n, initvalue=c))
+                want_or = int(np.bitwise_or.reduce(x[:n]))
+                assert int(got[0]) == want_or, (n, i, shift)
+                assert int(got[1]) == step, (n, i, shift, hex(int(got[1])))
+                assert (int(got[2]), int(got[3])) == (int(x[:n].min()), int(x[:n].max())), (n, i, shift)
+    # random data, exact
+    for n in (per_wg * 4 + 1234, 100001):
+        x = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+        got = to_np(dev.reduce_length(to_dev(x), n, initvalue=7))
+        d = np.diff(np.concatenate([[np.uint32(7)], x]).astype(np.uint32))
+        assert int(got[0]) == int(np.bitwise_or.reduce(x)) and int(got[1]) == int(np.bitwise_or.reduce(d))
+        assert (int(got[2]), int(got[3])) == (int(x.min()), int(x.max()))
