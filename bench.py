@@ -175,12 +175,12 @@ def make_ids(nblocks, b, seed, dev):
     return torch.cumsum(gaps, 0, dtype=torch.int32)  # wraps mod 2^32 like the reference's uint32 sums
 
 
-def build_corpus(nblocks, b, seed, dev):
+def build_corpus(nblocks, b, seed, dev, payload_out=None, offsets_out=None):
     """Encode the docIDs of make_ids on the device.  Returns (payload, offsets,
     [checksum of the decoded array, number of decode mismatches])."""
     ids = make_ids(nblocks, b, seed, dev)
-    offsets = torch.empty(nblocks, dtype=torch.int32, device=dev)
-    payload = codec.packd1(ids, b, initvalue=0, masked=False, initvalues_out=offsets)
+    offsets = torch.empty(nblocks, dtype=torch.int32, device=dev) if offsets_out is None else offsets_out
+    payload = codec.packd1(ids, b, initvalue=0, masked=False, initvalues_out=offsets, out=payload_out)
     back = codec.unpackd1(offsets, payload, nblocks, b)
     acc = codec.checksum(back, other=ids)
     torch.cuda.synchronize()
@@ -745,11 +745,38 @@ def main():
     corpora = {}
     verify = torch.zeros(2, dtype=torch.int64, device=dev)
     seed0 = 1000 * (first % 100003)
+    # The working set of the decode (payloads, offsets, output) lives in ONE allocation, cut into 2 MiB aligned slices.
+    # With an allocation per array the widths 8..15 and 20..29 (and b = 1) ran 3-5 points slower in most processes --
+    # which ones changed from process to process -- although the kernels fetch the same bytes: 79.3-80.0 % aggregate
+    # in six runs on four boxes against 80.5-81.2 % with one allocation (profiles/r02_arena_ab.log).
+    # SIMDCOMP_BENCH_ARENA=0 brings the separate allocations back, 1 leaves only the output outside, 3 puts the slices
+    # off the 2 MiB grid (for comparison runs).
+    arena = None
+    arena_mode = int(os.environ.get("SIMDCOMP_BENCH_ARENA", "2"))
+    if arena_mode:
+        two_mib = 2 << 20
+        # (SIMDCOMP_BENCH_ALIGN=a, comparison runs: every slice at an odd multiple of a instead of on the 2 MiB grid)
+        odd = int(os.environ.get("SIMDCOMP_BENCH_ALIGN", "0"))
+        skew = 4608 if arena_mode == 3 else 0
+        up = lambda x: (x + two_mib - 1) // two_mib * two_mib + skew
+        total = sum(up(nblocks * 16 * b) + up(nblocks * 4) for b in WIDTHS) + up(nblocks * 512) + 2 * two_mib
+        arena = torch.empty(total, dtype=torch.uint8, device=dev)
+        at = (-arena.data_ptr()) % two_mib + skew + odd
     for b in WIDTHS:
-        payload, offsets, acc = build_corpus(nblocks, b, seed=seed0 + b, dev=dev)
+        if arena is not None:
+            pay = arena[at:at + nblocks * 16 * b]
+            at += up(nblocks * 16 * b)
+            offs = arena[at:at + nblocks * 4].view(torch.int32)
+            at += up(nblocks * 4)
+            payload, offsets, acc = build_corpus(nblocks, b, seed=seed0 + b, dev=dev, payload_out=pay, offsets_out=offs)
+        else:
+            payload, offsets, acc = build_corpus(nblocks, b, seed=seed0 + b, dev=dev)
         corpora[b] = (payload, offsets)
         verify += acc
-    out = torch.empty(nblocks * 128, dtype=torch.int32, device=dev)
+    if arena_mode == 2:
+        out = arena[at:at + nblocks * 512].view(torch.int32)
+    else:
+        out = torch.empty(nblocks * 128, dtype=torch.int32, device=dev)
 
     def step(events=None):
         for b in WIDTHS:
@@ -826,6 +853,9 @@ def main():
                                    "simdunpackd1 with stored per-block offsets, one launch per width b=1..32 per step"
                                    % a.log2n,
                        "ints_per_gpu": nblocks * 128, "widths": "1..32", "sharding": "block range, no data-path collective",
+                       "allocation": {0: "one allocation per array", 1: "payloads and offsets in one allocation",
+                                      2: "payloads, offsets and output in one allocation (2 MiB aligned slices)",
+                                      3: "one allocation, slices off the 2 MiB grid"}.get(arena_mode, str(arena_mode)),
                        "launch": how},
             "verification": {"decode_mismatches": int(verify[1].item()), "checksum": int(verify[0].item()) & (2 ** 64 - 1)},
             "roofline": {"bound": "hbm", "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
@@ -867,6 +897,7 @@ def main():
         line["verification"]["sampled_blocks_vs_oracle_mismatches"] = cb.get("decode_vs_gpu_mismatches")
         line["verification"]["sampled_blocks_per_width"] = cb.get("blocks_compared_per_width")
     del corpora
+    arena = None
     torch.cuda.empty_cache()
     if rank == 0 and not a.no_callers and world == 1:
         line["callers"] = callers_leg(dev, a.log2n)
