@@ -578,3 +578,44 @@ def test_stream_copy_width_extremes(dev, pattern, nblk):
         got = back.cpu().numpy()
         assert np.array_equal(got[16:16 + nbytes], arena[:nbytes])
         assert (got[:16] == 0xCC).all() and (got[16 + nbytes:] == 0xCC).all(), "wrote outside the arena"
+
+
+def test_one_call_entry_points_under_graph_capture(dev):
+    """The batched entry points neither allocate nor synchronise, so a caller may capture them in a HIP graph:
+    compress and decode of the byte stream captured once, replayed on new input in the same buffers."""
+    import torch
+    from simdcomp_amd import binding
+
+    L, P = binding.lib(), binding.ptr
+    nblk = 5000
+    x = G.stream_corpus(321, nblk)
+    d_x = to_dev(x)
+    ws_k = torch.empty(L.simdcomp_hip_stream_compress_workspace(nblk), dtype=torch.uint8, device="cuda")
+    nb = torch.zeros(1, dtype=torch.int64, device="cuda")
+    strm = torch.zeros(513 * nblk, dtype=torch.uint8, device="cuda")
+    ws_d = torch.empty(L.simdcomp_hip_stream_decode_workspace(513 * nblk, nblk), dtype=torch.uint8, device="cuda")
+    out = torch.zeros(nblk * 128, dtype=torch.int32, device="cuda")
+    r3 = torch.zeros(3, dtype=torch.int64, device="cuda")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):  # (warm-up outside the capture: module loading is not capturable)
+        s = torch.cuda.current_stream().cuda_stream
+        binding.check(L.simdcomp_hip_stream_compress(D1, 0, P(d_x), nblk, P(strm), P(nb), P(ws_k), s), "compress")
+        binding.check(L.simdcomp_hip_stream_decode(D1, 0, P(strm), 513 * nblk, nblk, P(out), P(r3), P(ws_d), s), "decode")
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        s = torch.cuda.current_stream().cuda_stream
+        binding.check(L.simdcomp_hip_stream_compress(D1, 0, P(d_x), nblk, P(strm), P(nb), P(ws_k), s), "compress")
+        # the decoder is given the whole buffer: what lies behind the stream has to parse as records too, so the
+        # buffer is zero-filled (zero-width records) and max_blocks = nblk stops the index
+        binding.check(L.simdcomp_hip_stream_decode(D1, 0, P(strm), 513 * nblk, nblk, P(out), P(r3), P(ws_d), s), "decode")
+    for seed in (322, 323):
+        y = G.stream_corpus(seed, nblk)
+        d_x.copy_(to_dev(y))
+        strm.zero_()
+        out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(u32(out), y), seed
