@@ -29,6 +29,11 @@ Extra objects on the JSON line:
   callers       example.c's compress() and decode loop over the [width byte][payload]
                 stream as one device call each, and a batched simdsearchwithlengthd1,
                 on a mixed-width corpus; round trip and answers checked in place;
+  for           BASELINE configs[3]: clustered integers through the frame-of-reference
+                path (maxmin -> payload offsets -> pack_mixed / unpack_mixed), 2^30 per GPU;
+  mixed_d1      BASELINE configs[4] device-resident: one mixed-width d1 corpus over all
+                ranks, block-range shards from simdcomp_hip_partition_by_bytes, per-rank
+                bytes and times, verification pair summed over the ranks;
   host_to_host  the same decode including pinned H2D/D2H copies, at four uniform
                 widths and on a mixed-width (1..20 bits) corpus.
 roofline.traffic is measured in the same run at N = 1: after its own work rank 0
@@ -36,9 +41,10 @@ starts this script twice more as a child process under `rocprofv3 --pmc`
 (FETCH_SIZE, WRITE_SIZE; one step each) and averages the counters of the 32 decode
 launches (--no-traffic skips it; the committed summary of an earlier run,
 profiles/pmc_traffic_latest.json, is the fallback when the profiler is missing).
-`encode` and `host_to_host` run on every rank at the same time (each GPU has its
-own PCIe link; host memory is shared) and are reported per rank and summed;
-cpu_baseline and callers run at N = 1 only.
+`encode`, `for`, `mixed_d1` and `host_to_host` run on every rank at the same time
+(each GPU has its own PCIe link; host memory is shared) and are reported per rank
+and summed; cpu_baseline runs on rank 0 at every N (the other ranks wait without
+spinning); callers and the counter passes run at N = 1 only.
 
 Launching: under torch.distributed.run (RANK set) this process is one rank.
 Started plainly with --gpus N > 1 it is only a launcher: it touches no GPU, starts
@@ -142,12 +148,28 @@ def selftest(a, rank, world):
     words = synth.rand_u32(5, total_blocks * 128)[first * 128:(first + nblocks) * 128]
     idx = (np.arange(first * 128, (first + nblocks) * 128, dtype=np.uint64)) << np.uint64(32)
     chk = int(synth.splitmix64(idx ^ words.astype(np.uint64)).sum(dtype=np.uint64))
-    acc = torch.tensor([chk >> 32, chk & 0xFFFFFFFF, first, nblocks], dtype=torch.int64)
+    # the mixed-width corpus description and its shards by bytes (what mixed_d1_leg runs on the GPUs)
+    widths, prefix = corpus_description(total_blocks)
+    bfirst, bcount = codec.partition_by_bytes(prefix, world, rank)
+    cost = int(prefix[bfirst + bcount] - prefix[bfirst]) + 512 * bcount
+    acc = torch.tensor([chk >> 32, chk & 0xFFFFFFFF, first, nblocks, bcount, cost, int(widths[bfirst:bfirst + bcount].sum())],
+                       dtype=torch.int64)
+    ends = torch.zeros(world * 2, dtype=torch.int64)
+    ends[2 * rank], ends[2 * rank + 1] = bfirst, bfirst + bcount
+    costs = torch.zeros(world, dtype=torch.int64)
+    costs[rank] = cost
     dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+    dist.all_reduce(ends, op=dist.ReduceOp.SUM)
+    dist.all_reduce(costs, op=dist.ReduceOp.SUM)
     if rank == 0:
         got = acc.tolist()
+        e = ends.tolist()
         print_line({"selftest": True, "backend": "gloo", "n_gpus": dist.get_world_size(), "blocks": got[3],
-                    "sum_of_first": got[2], "checksum": ((got[0] << 32) + got[1]) & (2 ** 64 - 1)})
+                    "sum_of_first": got[2], "checksum": ((got[0] << 32) + got[1]) & (2 ** 64 - 1),
+                    "by_bytes": {"blocks": got[4], "cost_bytes": got[5], "sum_of_widths": got[6],
+                                 "whole_cost_bytes": int(prefix[-1]) + 512 * total_blocks, "whole_sum_of_widths": int(widths.sum()),
+                                 "contiguous": e[0] == 0 and e[-1] == total_blocks and all(e[2 * i + 1] == e[2 * i + 2] for i in range(world - 1)),
+                                 "cost_per_rank": costs.tolist(), "blocks_per_rank": [e[2 * i + 1] - e[2 * i] for i in range(world)]}})
     dist.barrier()
     dist.destroy_process_group()
 
@@ -195,6 +217,174 @@ def gather_floats(x, distributed, dev):
     out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
     dist.all_gather(out, t)
     return [float(o.item()) for o in out]
+
+
+def gather_rows(row, distributed, dev):
+    """A short list of numbers from every rank, in rank order (floats are exact for integers below 2^53)."""
+    if not distributed:
+        return [[float(v) for v in row]]
+    t = torch.tensor([float(v) for v in row], dtype=torch.float64, device=dev)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [[float(v) for v in o.tolist()] for o in out]
+
+
+def timed_launches(fn, reps, warm=1):
+    """Launch times of fn() from HIP events on the current stream: (average, best) in seconds over reps launches."""
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        e1.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e-3)
+    return sum(ts) / len(ts), min(ts)
+
+
+def for_leg(dev, barrier, distributed, log2n, rank, reps=5):
+    """BASELINE configs[3]: frame-of-reference coding of clustered integers, 2^log2n per GPU, on every rank at the
+    same time.  The caller's sequence of tests/unit.c:659-666 per block -- frame = simdmin, width = bits(max - min) --
+    as batched calls: simdcomp_hip_maxmin -> payload_offsets -> pack_mixed(FOR) -> unpack_mixed(FOR).  Round trip
+    compared on the device.  Rates are per rank (HIP events around each launch) and summed."""
+    n = 1 << log2n
+    nblk = n // 128
+    g = torch.Generator(device=dev)
+    g.manual_seed(900 + rank)
+    wid = torch.minimum(torch.randint(0, 25, (nblk,), device=dev, generator=g), torch.randint(0, 25, (nblk,), device=dev, generator=g))
+    x = torch.randint(0, 1 << 30, (n,), dtype=torch.int32, device=dev, generator=g)
+    x &= ((1 << wid) - 1).to(torch.int32).repeat_interleave(128)
+    base = torch.randint(-(1 << 31), (1 << 31) - 1, (nblk,), dtype=torch.int64, device=dev, generator=g).to(torch.int32)
+    x += base.repeat_interleave(128)  # cluster bases anywhere in 32 bits; the sums wrap like uint32
+    del wid, base
+    barrier()
+    res = {}
+    box = {}
+
+    def frames():
+        box["lo"], box["hi"], box["bits"] = codec.maxmin(x)
+
+    t_mm, _ = timed_launches(frames, reps)
+    lo, bits = box["lo"], box["bits"]
+    del box["hi"]
+    t_off, _ = timed_launches(lambda: box.__setitem__("off", codec.payload_offsets(bits)), reps)
+    off, total = box["off"]
+    nbytes = int(total.item())
+    arena = torch.empty(nbytes + 16, dtype=torch.uint8, device=dev)
+    t_enc, _ = timed_launches(lambda: codec.pack_mixed(binding.FOR, x, bits, off, arena, initvalues=lo), reps)
+    out = torch.empty(n, dtype=torch.int32, device=dev)
+    barrier()
+    t_dec, t_dec_best = timed_launches(lambda: codec.unpack_mixed(binding.FOR, arena, bits, off, nblk, initvalues=lo, out=out), reps)
+    acc = codec.checksum(out, other=x)
+    torch.cuda.synchronize()
+    bad = int(acc[1].item())
+    moved = nbytes + nblk * (512 + 4 + 1 + 8)  # payload + integers + frame, width and offset of every block
+    rows = gather_rows([n / t_dec, moved / t_dec / HBM_PEAK, n / t_enc, moved / t_enc / HBM_PEAK, n / t_mm, n * 4 / t_mm / HBM_PEAK,
+                        bad, nbytes * 8 / n, t_dec * 1e3, t_enc * 1e3, t_mm * 1e3, t_off * 1e3, moved / t_dec_best / HBM_PEAK], distributed, dev)
+    return {"what": "BASELINE configs[3]: clustered integers, 2^%d per GPU, per-block frame = simdmin and width = bits(max - min) "
+                    "(tests/unit.c:659-666): simdcomp_hip_maxmin -> payload_offsets -> pack_mixed(FOR) -> unpack_mixed(FOR)" % log2n,
+            "bytes_per_block": "512 + 16*b[k] + 4 (frame) + 1 (width) + 8 (offset)",
+            "timing": f"average of {reps} launches per call, HIP events, every rank at the same time",
+            "decode": {"aggregate_int32/s": sum(r[0] for r in rows), "min_frac": min(r[1] for r in rows)},
+            "encode": {"aggregate_int32/s": sum(r[2] for r in rows), "min_frac": min(r[3] for r in rows)},
+            "frames": {"aggregate_int32/s": sum(r[4] for r in rows), "min_frac": min(r[5] for r in rows)},
+            "round_trip_mismatches": int(sum(r[6] for r in rows)),
+            "per_rank": [{"decode_int32/s": r[0], "decode_frac": round(r[1], 4), "decode_frac_fastest_launch": round(r[12], 4),
+                          "encode_int32/s": r[2], "encode_frac": round(r[3], 4),
+                          "maxmin_int32/s": r[4], "maxmin_frac": round(r[5], 4), "round_trip_mismatches": int(r[6]),
+                          "bits_per_int": round(r[7], 3), "decode_ms": round(r[8], 4), "encode_ms": round(r[9], 4),
+                          "maxmin_ms": round(r[10], 4), "offsets_scan_ms": round(r[11], 4)} for r in rows]}
+
+
+MIXED_SEED = 41
+
+
+def corpus_description(total_blocks):
+    """The global mixed-width corpus of BASELINE configs[4] as every rank can compute it by itself: the width of
+    every block (counter-based, growing along the corpus: 1..8 bits at its start, 1..20 at its end) and the
+    exclusive prefix of the payload bytes, total_blocks + 1 entries in host memory -- the array
+    simdcomp_hip_partition_by_bytes cuts on."""
+    from simdcomp_amd import synth
+
+    widths = synth.ramped_widths(MIXED_SEED, total_blocks, 1, 8, 20)
+    prefix = np.zeros(total_blocks + 1, dtype=np.uint64)
+    np.cumsum(widths.astype(np.uint64) * np.uint64(16), out=prefix[1:])
+    return widths, prefix
+
+
+def mixed_d1_leg(dev, barrier, distributed, log2n, rank, world, reps=5):
+    """BASELINE configs[4], device-resident: ONE mixed-width d1 corpus of world * 2^log2n docIDs, sharded by block range.
+    Every rank computes the corpus description (widths, payload prefix), takes its range from
+    simdcomp_hip_partition_by_bytes (equal payload + output bytes, not equal block counts), builds the docIDs of its
+    range on its GPU, encodes (simdmaxbitsd1 chained -> payload_offsets -> pack_mixed) and decodes (unpack_mixed) them.
+    The widths the encoder finds must be the description's; the verification pair (decode mismatches, checksum with
+    global indices) is summed over the ranks by the caller."""
+    per = (1 << log2n) // 128
+    total_blocks = world * per
+    widths, prefix = corpus_description(total_blocks)
+    first, count = codec.partition_by_bytes(prefix, world, rank)
+    assert count > 0
+    n = count * 128
+    w = torch.from_numpy(widths[first:first + count].copy()).to(dev)
+    del widths
+    want_bytes = int(prefix[first + count] - prefix[first])
+    g = torch.Generator(device=dev)
+    g.manual_seed(7000 + first % 1000003)
+    gaps = torch.randint(0, 1 << 30, (n,), dtype=torch.int32, device=dev, generator=g)
+    wi = w.to(torch.int32)
+    gaps &= ((1 << wi) - 1).repeat_interleave(128)
+    gaps.view(count, 128)[:, 0] |= 1 << (wi - 1)  # every block needs exactly its width
+    start = (first * 2654435761) & 0x7FFFFFFF  # the docID in front of this range: any value, d1 coding is translation invariant
+    ids = torch.cumsum(gaps, 0, dtype=torch.int32)
+    ids += start
+    del gaps, wi
+    seeds = torch.empty(count, dtype=torch.int32, device=dev)
+    barrier()
+    box = {}
+    t_bits, _ = timed_launches(lambda: box.__setitem__("bits", codec.maxbitsd1(ids, initvalue=start, initvalues_out=seeds)), reps)
+    bits = box["bits"]
+    widths_ok = bool(torch.equal(bits, w))
+    del w
+    off, total = codec.payload_offsets(bits)
+    nbytes = int(total.item())
+    arena = torch.empty(nbytes + 16, dtype=torch.uint8, device=dev)
+    t_enc, _ = timed_launches(lambda: codec.pack_mixed(binding.D1, ids, bits, off, arena, initvalues=seeds, masked=False), reps)
+    out = torch.empty(n, dtype=torch.int32, device=dev)
+    barrier()
+    t0 = time.perf_counter()
+    t_dec, t_dec_best = timed_launches(lambda: codec.unpack_mixed(binding.D1, arena, bits, off, count, initvalues=seeds, out=out), reps)
+    barrier()
+    wall = time.perf_counter() - t0
+    acc = codec.checksum(out, other=ids, index0=first * 128)
+    torch.cuda.synchronize()
+    moved = nbytes + count * (512 + 4 + 1 + 8)
+    rows = gather_rows([first, count, nbytes, t_dec * 1e3, moved / t_dec / HBM_PEAK, t_enc * 1e3, moved / t_enc / HBM_PEAK,
+                        t_bits * 1e3, int(widths_ok and nbytes == want_bytes), moved / t_dec_best / HBM_PEAK], distributed, dev)
+    if distributed:
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+    ints = sum(r[1] for r in rows) * 128
+    cost = [r[2] + r[1] * 512 for r in rows]
+    return {"what": "BASELINE configs[4], device-resident: one d1 corpus of %d x 2^%d docIDs with per-block widths (1..8 bits at its "
+                    "start, 1..20 at its end), block-range shards from simdcomp_hip_partition_by_bytes; per rank "
+                    "simdcomp_hip_maxbitsd1 (chained) -> payload_offsets -> pack_mixed(D1) -> unpack_mixed(D1)" % (world, log2n),
+            "bytes_per_block": "512 + 16*b[k] + 4 (offset) + 1 (width) + 8 (payload offset)",
+            "timing": f"average of {reps} launches per call, HIP events, every rank at the same time",
+            "total_blocks": total_blocks, "blocks_covered": int(sum(r[1] for r in rows)),
+            "shards_contiguous": all(int(rows[i][0] + rows[i][1]) == int(rows[i + 1][0]) for i in range(len(rows) - 1)) and int(rows[0][0]) == 0,
+            "widths_match_description": all(int(r[8]) == 1 for r in rows),
+            "decode_mismatches": int(acc[1].item()), "checksum": int(acc[0].item()) & (2 ** 64 - 1),
+            "decode": {"aggregate_int32/s": ints / max(r[3] for r in rows) * 1e3, "min_frac": min(r[4] for r in rows)},
+            "encode": {"aggregate_int32/s": ints / max(r[5] for r in rows) * 1e3, "min_frac": min(r[6] for r in rows)},
+            "imbalance": {"cost_bytes_max_over_mean": round(max(cost) / (sum(cost) / len(cost)), 5),
+                          "blocks_max_over_mean": round(max(r[1] for r in rows) / (sum(r[1] for r in rows) / len(rows)), 5),
+                          "decode_ms_max_over_mean": round(max(r[3] for r in rows) / (sum(r[3] for r in rows) / len(rows)), 4)},
+            "wall_s_decode_launches_rank0": round(wall, 4),
+            "per_rank": [{"first_block": int(r[0]), "blocks": int(r[1]), "payload_bytes": int(r[2]), "cost_bytes": int(r[2] + 512 * r[1]),
+                          "bits_per_int": round(r[2] * 8 / (r[1] * 128), 3), "decode_ms": round(r[3], 4), "decode_frac": round(r[4], 4),
+                          "decode_frac_fastest_launch": round(r[9], 4), "encode_ms": round(r[5], 4), "encode_frac": round(r[6], 4),
+                          "maxbitsd1_ms": round(r[7], 4)} for r in rows]}
 
 
 def encode_leg(corpora, nblocks, seed0, dev, reps=3):
@@ -287,7 +477,7 @@ def live_traffic(log2n, nblocks, with_encode):
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(tmp, ctr)
             cmd = [tool, "--pmc", ctr, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
-                   "--steps", "1", "--warmup", "0", "--log2n", str(log2n), "--no-cpu", "--no-h2h", "--no-callers", "--no-traffic"]
+                   "--steps", "1", "--warmup", "0", "--log2n", str(log2n), "--no-cpu", "--no-h2h", "--no-callers", "--no-traffic", "--no-for", "--no-mixed"]
             if not with_encode:
                 cmd.append("--no-encode")
             child = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
@@ -701,6 +891,8 @@ def main():
     ap.add_argument("--no-h2h", action="store_true", help="skip the host-to-host leg")
     ap.add_argument("--no-encode", action="store_true", help="skip the encoder leg")
     ap.add_argument("--no-callers", action="store_true", help="skip the stream / search leg")
+    ap.add_argument("--no-for", action="store_true", help="skip the frame-of-reference leg (configs[3])")
+    ap.add_argument("--no-mixed", action="store_true", help="skip the mixed-width d1 leg (configs[4], device-resident)")
     ap.add_argument("--no-traffic", action="store_true", help="do not re-run under rocprofv3 --pmc for roofline.traffic")
     ap.add_argument("--selftest", action="store_true", help="CPU-only check of the multi-rank plumbing (gloo)")
     a = ap.parse_args()
@@ -737,6 +929,7 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         assert dist.get_world_size() == a.gpus, (dist.get_world_size(), a.gpus)
+        wait_group = dist.new_group(backend="gloo")  # for waits that must not spin (see cpu_baseline below)
 
     # block-range shard of the global corpus (weak scaling: 2^log2n docIDs per GPU)
     total_blocks = world * ((1 << a.log2n) // 128)
@@ -890,15 +1083,29 @@ def main():
             enc["aggregate_unit"] = "int32/s over all GPUs"
             enc["widths_with_wrong_bytes"] = int(sum(wrong))
             line["encode"] = enc
-    # cpu_baseline and callers run at N = 1 only: at N > 1 the other ranks would sit in a barrier while rank 0 works
-    if rank == 0 and not a.no_cpu and world == 1:
-        cb = cpu_baseline(corpora, dev)
-        line["cpu_baseline"] = cb
-        line["verification"]["sampled_blocks_vs_oracle_mismatches"] = cb.get("decode_vs_gpu_mismatches")
-        line["verification"]["sampled_blocks_per_width"] = cb.get("blocks_compared_per_width")
+    # cpu_baseline: rank 0 only, outside every timed region.  At N > 1 the other ranks wait for it in a barrier of a
+    # gloo group (a blocked socket read: they keep no host core busy while the reference is being timed)
+    if not a.no_cpu:
+        if rank == 0:
+            cb = cpu_baseline(corpora, dev)
+            line["cpu_baseline"] = cb
+            line["verification"]["sampled_blocks_vs_oracle_mismatches"] = cb.get("decode_vs_gpu_mismatches")
+            line["verification"]["sampled_blocks_per_width"] = cb.get("blocks_compared_per_width")
+        if distributed:
+            dist.barrier(group=wait_group)
     del corpora
     arena = None
     torch.cuda.empty_cache()
+    if not a.no_for:
+        fl = for_leg(dev, barrier, distributed, a.log2n, rank)
+        if rank == 0:
+            line["for"] = fl
+        torch.cuda.empty_cache()
+    if not a.no_mixed:
+        ml = mixed_d1_leg(dev, barrier, distributed, a.log2n, rank, world)
+        if rank == 0:
+            line["mixed_d1"] = ml
+        torch.cuda.empty_cache()
     if rank == 0 and not a.no_callers and world == 1:
         line["callers"] = callers_leg(dev, a.log2n)
         torch.cuda.empty_cache()
@@ -920,7 +1127,7 @@ def main():
         else:
             line["roofline"]["traffic_live_failed"] = detail
     if not a.no_h2h:
-        h2h = host_to_host(dev, barrier, distributed)
+        h2h = host_to_host(dev, barrier, distributed, log2n=min(28, a.log2n))
         if rank == 0:
             line["host_to_host"] = h2h
     if rank == 0:

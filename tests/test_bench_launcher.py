@@ -40,6 +40,15 @@ def test_launcher_starts_n_ranks(gpus):
     # shards are contiguous and equal: firsts are 0, 1001, 2002, ...
     assert doc["sum_of_first"] == 1001 * gpus * (gpus - 1) // 2
     assert doc["checksum"] == whole_checksum(gpus * 1001)
+    # shards by bytes (simdcomp_hip_partition_by_bytes over the mixed-width corpus description): contiguous, cover
+    # the corpus once, and no shard's cost is further from the mean than one block's
+    bb = doc["by_bytes"]
+    assert bb["contiguous"] and bb["blocks"] == gpus * 1001
+    assert bb["cost_bytes"] == bb["whole_cost_bytes"] and bb["sum_of_widths"] == bb["whole_sum_of_widths"]
+    mean = bb["whole_cost_bytes"] / gpus
+    assert all(abs(c - mean) <= 512 + 16 * 20 for c in bb["cost_per_rank"]), bb
+    if gpus > 1:  # the corpus gets wider along the way: equal bytes are not equal block counts
+        assert bb["blocks_per_rank"][0] > bb["blocks_per_rank"][-1], bb
 
 
 def test_world_size_must_match_gpus():
@@ -63,7 +72,7 @@ def test_two_ranks_share_one_gpu():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
     env["SIMDCOMP_BENCH_SHARE_GPU"] = "1"
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--log2n", "22", "--steps", "2",
-                          "--warmup", "1", "--no-h2h"], capture_output=True, text=True, timeout=300, env=env)
+                          "--warmup", "1"], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout
@@ -73,3 +82,13 @@ def test_two_ranks_share_one_gpu():
     assert doc["verification"]["decode_mismatches"] == 0
     assert len(doc["roofline"]["per_rank_frac"]) == 2
     assert len(doc["encode"]["per_rank_value"]) == 2 and doc["encode"]["widths_with_wrong_bytes"] == 0
+    # every leg an 8-GPU line carries has run with two ranks: frame of reference, the mixed-width d1 corpus cut by
+    # simdcomp_hip_partition_by_bytes, host to host, and the CPU baseline on rank 0
+    assert len(doc["for"]["per_rank"]) == 2 and doc["for"]["round_trip_mismatches"] == 0
+    md = doc["mixed_d1"]
+    assert len(md["per_rank"]) == 2 and md["decode_mismatches"] == 0
+    assert md["shards_contiguous"] and md["widths_match_description"] and md["blocks_covered"] == md["total_blocks"]
+    assert md["per_rank"][0]["blocks"] > md["per_rank"][1]["blocks"]  # equal bytes, not equal block counts
+    assert md["imbalance"]["cost_bytes_max_over_mean"] < 1.001
+    assert doc["host_to_host"]["ranks"] == 2 and doc["host_to_host"]["per_width"]["mixed"]["round_trip_ok"]
+    assert doc["cpu_baseline"]["decode_vs_gpu_mismatches"] == 0 and doc["cpu_baseline"]["value"] > 0
