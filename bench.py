@@ -34,8 +34,9 @@ Extra objects on the JSON line:
   mixed_d1      BASELINE configs[4] device-resident: one mixed-width d1 corpus over all
                 ranks, block-range shards from simdcomp_hip_partition_by_bytes, per-rank
                 bytes and times, verification pair summed over the ranks;
-  host_to_host  the same decode including pinned H2D/D2H copies, at four uniform
-                widths and on a mixed-width (1..20 bits) corpus.
+  host_to_host  the same decode starting and ending in pinned host memory (H2D payload,
+                kernel, D2H integers on three streams; and in place on the pinned buffers),
+                at four uniform widths and on a mixed-width (1..20 bits) corpus.
 roofline.traffic is measured in the same run at N = 1: after its own work rank 0
 starts this script twice more as a child process under `rocprofv3 --pmc`
 (FETCH_SIZE, WRITE_SIZE; one step each) and averages the counters of the 32 decode
@@ -782,16 +783,54 @@ def callers_leg(dev, log2n):
 # ---------------------------------------------------------------------------------------------------------------
 # host to host
 # ---------------------------------------------------------------------------------------------------------------
+class Pipeline:
+    """Host-to-host pieces on three streams -- uploads, kernels, downloads -- chained by events, `depth` sets of device
+    buffers.  With one stream per piece (upload, kernel, download in a row on it, two pieces alternating) each
+    direction of the link idles half of the time: 7.0 against 10.9 G int32/s at 32 bits
+    (profiles/r03_duplex_probe.json)."""
+
+    def __init__(self, depth=3):
+        self.depth = depth
+        self.up, self.kernel, self.down = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+
+    def run(self, pieces, upload, launch, download):
+        kernel_done = [None] * self.depth
+        down_done = [None] * self.depth
+        for i, piece in enumerate(pieces):
+            q = i % self.depth
+            with torch.cuda.stream(self.up):
+                if kernel_done[q] is not None:
+                    self.up.wait_event(kernel_done[q])  # the kernel that read this slot's input
+                upload(q, piece)
+                up_done = self.up.record_event()
+            with torch.cuda.stream(self.kernel):
+                self.kernel.wait_event(up_done)
+                if down_done[q] is not None:
+                    self.kernel.wait_event(down_done[q])  # the download that read this slot's output
+                launch(q, piece)
+                kernel_done[q] = self.kernel.record_event()
+            with torch.cuda.stream(self.down):
+                self.down.wait_event(kernel_done[q])
+                download(q, piece)
+                down_done[q] = self.down.record_event()
+        torch.cuda.synchronize()
+
+
 def host_to_host(dev, barrier, distributed, log2n=28, widths=(1, 8, 16, 32)):
-    """Decode that starts and ends in pinned host memory: H2D payload (+ offsets, widths), kernel, D2H integers,
-    pipelined in 2^24-integer pieces over two streams.  Every rank runs it on its own GPU at the same time (a barrier
-    in front of every timed pass): `per_rank` lists each rank's rate, `aggregate` their sum.  The `mixed` case is the
-    per-block-width d1 corpus of BASELINE configs[4] (widths 1..20): widths, payload offsets and seeds travel with
-    the payload, and simdcomp_hip_unpack_mixed decodes a piece."""
+    """Decode that starts and ends in pinned host memory, two ways:
+      staged    H2D payload (+ offsets, widths), kernel, D2H integers in 2^24-integer pieces through the three-stream
+                Pipeline above;
+      in_place  one launch whose kernel reads the payload from the pinned host buffer and writes the integers to the
+                pinned host buffer itself (no copies, no device buffers).
+    Every rank runs it on its own GPU at the same time (a barrier in front of every timed pass): `per_rank` lists
+    each rank's rate, the headline figures their sum.  The `mixed` case is the per-block-width d1 corpus of BASELINE
+    configs[4] (widths 1..20): widths, payload offsets and seeds travel with the payload, and
+    simdcomp_hip_unpack_mixed decodes a piece."""
     n = 1 << log2n
     nblk = n // 128
     piece = 1 << 17  # blocks per piece (2^24 integers)
-    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    depth = 3
+    pipe = Pipeline(depth)
     h_out = torch.empty(n, dtype=torch.int32, pin_memory=True)
     L, P = binding.lib(), binding.ptr
 
@@ -805,30 +844,48 @@ def host_to_host(dev, barrier, distributed, log2n=28, widths=(1, 8, 16, 32)):
             best = min(best, time.perf_counter() - t0)
         return best
 
+    def row(t_staged, t_place, pcie, extra=None):
+        rs = gather_floats(n / t_staged, distributed, dev)
+        rp = gather_floats(n / t_place, distributed, dev)
+        r = {"Gint/s": round(sum(rs) / 1e9, 2), "GB/s_over_pcie": round(sum(rs) / n * pcie / 1e9, 1),
+             "per_rank_Gint/s": [round(v / 1e9, 2) for v in rs],
+             "in_place_Gint/s": round(sum(rp) / 1e9, 2), "in_place_GB/s_over_pcie": round(sum(rp) / n * pcie / 1e9, 1),
+             "in_place_per_rank_Gint/s": [round(v / 1e9, 2) for v in rp]}
+        r.update(extra or {})
+        return r
+
     res = {}
     h_off = torch.empty(nblk, dtype=torch.int32, pin_memory=True).fill_(12345)
-    d_out = [torch.empty(piece * 128, dtype=torch.int32, device=dev) for _ in range(2)]
+    d_out = [torch.empty(piece * 128, dtype=torch.int32, device=dev) for _ in range(depth)]
+    firsts = list(range(0, nblk, piece))
     for b in widths:
         h_pay = torch.empty(nblk * 16 * b, dtype=torch.uint8, pin_memory=True).fill_(0x5B)
-        d_pay = [torch.empty(piece * 16 * b, dtype=torch.uint8, device=dev) for _ in range(2)]
-        d_off = [torch.empty(piece, dtype=torch.int32, device=dev) for _ in range(2)]
+        d_pay = [torch.empty(piece * 16 * b, dtype=torch.uint8, device=dev) for _ in range(depth)]
+        d_off = [torch.empty(piece, dtype=torch.int32, device=dev) for _ in range(depth)]
 
-        def run():
-            for i, first in enumerate(range(0, nblk, piece)):
-                s = i & 1
-                with torch.cuda.stream(streams[s]):
-                    cnt = min(piece, nblk - first)
-                    d_pay[s][: cnt * 16 * b].copy_(h_pay[first * 16 * b:(first + cnt) * 16 * b], non_blocking=True)
-                    d_off[s][:cnt].copy_(h_off[first:first + cnt], non_blocking=True)
-                    codec.unpackd1(d_off[s], d_pay[s], cnt, b, out=d_out[s])
-                    h_out[first * 128:(first + cnt) * 128].copy_(d_out[s][: cnt * 128], non_blocking=True)
+        def upload(q, first):
+            cnt = min(piece, nblk - first)
+            d_pay[q][: cnt * 16 * b].copy_(h_pay[first * 16 * b:(first + cnt) * 16 * b], non_blocking=True)
+            d_off[q][:cnt].copy_(h_off[first:first + cnt], non_blocking=True)
+
+        def launch(q, first):
+            codec.unpackd1(d_off[q], d_pay[q], min(piece, nblk - first), b, out=d_out[q])
+
+        def download(q, first):
+            cnt = min(piece, nblk - first)
+            h_out[first * 128:(first + cnt) * 128].copy_(d_out[q][: cnt * 128], non_blocking=True)
+
+        t_staged = timed(lambda: pipe.run(firsts, upload, launch, download))
+        staged_sum = int(h_out.sum(dtype=torch.int64).item())
+
+        def in_place():
+            binding.check(L.simdcomp_hip_unpackd1(P(h_off), P(h_pay), P(h_out), nblk, b, torch.cuda.current_stream().cuda_stream), "unpackd1")
             torch.cuda.synchronize()
 
-        best = timed(run)
-        rates = gather_floats(n / best, distributed, dev)
-        pcie = n * 4 + nblk * (16 * b + 4)
-        res[str(b)] = {"Gint/s": round(sum(rates) / 1e9, 2), "GB/s_over_pcie": round(sum(rates) / n * pcie / 1e9, 1),
-                       "per_rank_Gint/s": [round(r / 1e9, 2) for r in rates]}
+        h_out.zero_()
+        t_place = timed(in_place)
+        same = int(h_out.sum(dtype=torch.int64).item()) == staged_sum
+        res[str(b)] = row(t_staged, t_place, n * 4 + nblk * (16 * b + 4), {"staged_equals_in_place": same})
         del h_pay, d_pay, d_off
 
     # mixed widths: build the corpus on the device, keep it in pinned host memory the way an index file would be
@@ -845,39 +902,50 @@ def host_to_host(dev, barrier, distributed, log2n=28, widths=(1, 8, 16, 32)):
     h_offs = torch.empty(nblk, dtype=torch.int64, pin_memory=True).copy_(off_d)
     h_seeds = torch.empty(nblk, dtype=torch.int32, pin_memory=True).copy_(seeds_d)
     del ids, arena, bits_d, off_d, seeds_d
-    firsts = list(range(0, nblk, piece))
-    lo = [int(h_offs[f]) for f in firsts]
-    hi = lo[1:] + [total]
-    cap = max(h - l for l, h in zip(lo, hi))
-    d_pay = [torch.empty(cap + 16, dtype=torch.uint8, device=dev) for _ in range(2)]
-    d_bits = [torch.empty(piece, dtype=torch.uint8, device=dev) for _ in range(2)]
-    d_offs = [torch.empty(piece, dtype=torch.int64, device=dev) for _ in range(2)]
-    d_seeds = [torch.empty(piece, dtype=torch.int32, device=dev) for _ in range(2)]
+    lo = {f: int(h_offs[f]) for f in firsts}
+    hi = {f: (int(h_offs[f + piece]) if f + piece < nblk else total) for f in firsts}
+    cap = max(hi[f] - lo[f] for f in firsts)
+    d_pay = [torch.empty(cap + 16, dtype=torch.uint8, device=dev) for _ in range(depth)]
+    d_bits = [torch.empty(piece, dtype=torch.uint8, device=dev) for _ in range(depth)]
+    d_offs = [torch.empty(piece, dtype=torch.int64, device=dev) for _ in range(depth)]
+    d_seeds = [torch.empty(piece, dtype=torch.int32, device=dev) for _ in range(depth)]
 
-    def run_mixed():
-        for i, first in enumerate(firsts):
-            s = i & 1
-            with torch.cuda.stream(streams[s]):
-                cnt = min(piece, nblk - first)
-                d_pay[s][: hi[i] - lo[i]].copy_(h_pay[lo[i]:hi[i]], non_blocking=True)
-                d_bits[s][:cnt].copy_(h_bits[first:first + cnt], non_blocking=True)
-                d_offs[s][:cnt].copy_(h_offs[first:first + cnt], non_blocking=True)
-                d_seeds[s][:cnt].copy_(h_seeds[first:first + cnt], non_blocking=True)
-                # the offsets are those of the whole arena: the piece's payload pointer is moved back by the
-                # offset of its first block
-                binding.check(L.simdcomp_hip_unpack_mixed(1, P(d_seeds[s]), d_pay[s].data_ptr() - lo[i], P(d_offs[s]), P(d_bits[s]),
-                                                          P(d_out[s]), cnt, torch.cuda.current_stream().cuda_stream), "unpack_mixed")
-                h_out[first * 128:(first + cnt) * 128].copy_(d_out[s][: cnt * 128], non_blocking=True)
+    def upload_mixed(q, first):
+        cnt = min(piece, nblk - first)
+        d_pay[q][: hi[first] - lo[first]].copy_(h_pay[lo[first]:hi[first]], non_blocking=True)
+        d_bits[q][:cnt].copy_(h_bits[first:first + cnt], non_blocking=True)
+        d_offs[q][:cnt].copy_(h_offs[first:first + cnt], non_blocking=True)
+        d_seeds[q][:cnt].copy_(h_seeds[first:first + cnt], non_blocking=True)
+
+    def launch_mixed(q, first):
+        # the offsets are those of the whole arena: the piece's payload pointer is moved back by the offset of its
+        # first block
+        binding.check(L.simdcomp_hip_unpack_mixed(1, P(d_seeds[q]), d_pay[q].data_ptr() - lo[first], P(d_offs[q]), P(d_bits[q]),
+                                                  P(d_out[q]), min(piece, nblk - first), torch.cuda.current_stream().cuda_stream), "unpack_mixed")
+
+    def download_mixed(q, first):
+        cnt = min(piece, nblk - first)
+        h_out[first * 128:(first + cnt) * 128].copy_(d_out[q][: cnt * 128], non_blocking=True)
+
+    h_out.zero_()
+    t_staged = timed(lambda: pipe.run(firsts, upload_mixed, launch_mixed, download_mixed))
+    ok = bool(torch.equal(h_out, h_ids))
+
+    def in_place_mixed():
+        binding.check(L.simdcomp_hip_unpack_mixed(1, P(h_seeds), P(h_pay), P(h_offs), P(h_bits), P(h_out), nblk,
+                                                  torch.cuda.current_stream().cuda_stream), "unpack_mixed")
         torch.cuda.synchronize()
 
-    best = timed(run_mixed)
-    ok = bool(torch.equal(h_out, h_ids))
-    rates = gather_floats(n / best, distributed, dev)
-    pcie = n * 4 + total + nblk * 13
-    res["mixed"] = {"Gint/s": round(sum(rates) / 1e9, 2), "GB/s_over_pcie": round(sum(rates) / n * pcie / 1e9, 1),
-                    "per_rank_Gint/s": [round(r / 1e9, 2) for r in rates], "bits_per_int": round(total * 8 / n, 2),
-                    "round_trip_ok": ok, "what": "d1, per-block widths 1..20 (BASELINE configs[4] shape), simdcomp_hip_unpack_mixed"}
-    return {"ints_per_rank": n, "pinned": True, "ranks": len(rates), "per_width": res}
+    h_out.zero_()
+    t_place = timed(in_place_mixed)
+    ok_place = bool(torch.equal(h_out, h_ids))
+    res["mixed"] = row(t_staged, t_place, n * 4 + total + nblk * 13,
+                       {"bits_per_int": round(total * 8 / n, 2), "round_trip_ok": ok, "in_place_round_trip_ok": ok_place,
+                        "what": "d1, per-block widths 1..20 (BASELINE configs[4] shape), simdcomp_hip_unpack_mixed"})
+    return {"ints_per_rank": n, "pinned": True, "ranks": len(res["mixed"]["per_rank_Gint/s"]),
+            "staged": "three streams (uploads, kernels, downloads) chained by events, 3 sets of device buffers, 2^24-integer pieces",
+            "in_place": "one launch on the pinned host buffers themselves (the kernel's loads and stores cross the host link)",
+            "per_width": res}
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -11,20 +11,17 @@
 #include "codec_kernels.h"
 #include "stream_kernels.h"
 #include "query_kernels.h"
+#include "api_error.h"
 
 namespace {
 
-thread_local char g_err[256] = "";
-
-int fail(int code, const char *what) {
-  snprintf(g_err, sizeof g_err, "%s", what);
-  return code;
-}
+int fail(int code, const char *what) { return sc::api_fail(code, what); }
 
 int hip_result(hipError_t e, const char *where) {
   if (e == hipSuccess) return SIMDCOMP_HIP_OK;
-  snprintf(g_err, sizeof g_err, "%s: %s", where, hipGetErrorString(e));
-  return (int)e;
+  char msg[256];
+  snprintf(msg, sizeof msg, "%s: %s", where, hipGetErrorString(e));
+  return sc::api_fail((int)e, msg);
 }
 
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -91,10 +88,6 @@ int do_unpack(int mode, uint32_t seed0, const uint32_t *seeds, const void *paylo
 }  // namespace
 
 extern "C" {
-
-int simdcomp_hip_version(void) { return 100; }
-
-const char *simdcomp_hip_last_error(void) { return g_err; }
 
 int simdcomp_hip_pack(const uint32_t *d_in, void *d_out, size_t nblocks, uint32_t bit, int masked, void *stream) {
   return do_pack(sc::MODE_PLAIN, masked, 0, nullptr, d_in, d_out, nullptr, nullptr, bit, nblocks, nullptr, stream);
@@ -269,12 +262,6 @@ int simdcomp_hip_payload_offsets_noalloc(const uint8_t *d_bits, size_t nblocks, 
                     "payload offsets launch");
 }
 
-size_t simdcomp_hip_compressedbytes(size_t length, uint32_t bit) {
-  if (bit == 0) return 0;
-  if (bit >= 32) return length * 4;
-  return (((length + 3) / 4) * (size_t)bit + 31) / 32 * 16;
-}
-
 int simdcomp_hip_pack_length(const uint32_t *d_in, size_t length, void *d_out, uint32_t bit, void *stream) {
   if (bit > 32) return fail(SIMDCOMP_HIP_EBIT, "bit width > 32");
   if (length == 0 || bit == 0) return SIMDCOMP_HIP_OK;
@@ -346,40 +333,6 @@ int simdcomp_hip_packFOR_length(uint32_t initvalue, const uint32_t *d_in, size_t
 int simdcomp_hip_unpackFOR_length(uint32_t initvalue, const void *d_in, size_t length, uint32_t *d_out,
                                   uint32_t bit, void *stream) {
   return unpack_length_common(sc::MODE_FOR, initvalue, d_in, length, d_out, bit, stream);
-}
-
-int simdcomp_hip_partition(size_t nblocks, int nparts, int part, size_t *first, size_t *count) {
-  if (nparts <= 0 || part < 0 || part >= nparts || !first || !count) return fail(SIMDCOMP_HIP_ESIZE, "bad partition");
-  const size_t lo = (size_t)((unsigned __int128)nblocks * (unsigned)part / (unsigned)nparts);
-  const size_t hi = (size_t)((unsigned __int128)nblocks * (unsigned)(part + 1) / (unsigned)nparts);
-  *first = lo;
-  *count = hi - lo;
-  return SIMDCOMP_HIP_OK;
-}
-
-int simdcomp_hip_partition_by_bytes(const uint64_t *h_payload_offsets, size_t nblocks, int nparts, int part,
-                                    size_t *first, size_t *count) {
-  if (nparts <= 0 || part < 0 || part >= nparts || !first || !count || (!h_payload_offsets && nblocks))
-    return fail(SIMDCOMP_HIP_ESIZE, "bad partition");
-  // cost of blocks [0, k): payload bytes read + 512 bytes written per block
-  auto cost = [&](size_t k) -> unsigned __int128 {
-    return (unsigned __int128)(h_payload_offsets[k] - h_payload_offsets[0]) + (unsigned __int128)k * 512u;
-  };
-  auto cut = [&](int p) -> size_t {
-    if (p <= 0) return 0;
-    if (p >= nparts) return nblocks;
-    const unsigned __int128 target = cost(nblocks) * (unsigned)p / (unsigned)nparts;
-    size_t lo = 0, hi = nblocks;  // first k with cost(k) >= target
-    while (lo < hi) {
-      const size_t mid = lo + (hi - lo) / 2;
-      if (cost(mid) < target) lo = mid + 1; else hi = mid;
-    }
-    return lo;
-  };
-  const size_t a = nblocks ? cut(part) : 0, b = nblocks ? cut(part + 1) : 0;
-  *first = a;
-  *count = b - a;
-  return SIMDCOMP_HIP_OK;
 }
 
 size_t simdcomp_hip_chain_workspace(size_t nblocks) { return sc::chain_workspace_bytes(nblocks); }

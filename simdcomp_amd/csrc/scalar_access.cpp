@@ -70,7 +70,10 @@ int simdsearchwithlengthFOR(uint32_t initvalue, const __m128i *in, uint32_t bit,
       span = half;
     }
   }
-  *presult = simdselectFOR(initvalue, in, bit, lo);
+  // nothing found among all 128 values: the reference reads the value "at slot 128", i.e. whatever follows the
+  // block in the caller's memory; here that read is not made and the value reported is 0, as in the batched form
+  // (a 0-bit block has no memory behind its values: the answer is the base, as in the reference)
+  *presult = lo < 128 || bit == 0 ? simdselectFOR(initvalue, in, bit, lo) : 0u;
   return lo;
 }
 

@@ -47,6 +47,7 @@ namespace sc {
 #ifndef SC_SUMS_U
 #define SC_SUMS_U 8
 #endif
+__constant__ u32x4 g_sixteen_zero_bytes = {0, 0, 0, 0};  // device code cannot write it; k_block_sums depends on its value
 constexpr int SUMS_U = SC_SUMS_U;
 constexpr size_t SUMS_PER_WG = 8 * SUMS_U;
 
@@ -59,14 +60,17 @@ __global__ __launch_bounds__(256) void k_block_sums(const uint8_t *payload, cons
   const int h = lane >> 5, k = lane & 31;
   const size_t tile = blockIdx.x;
   u32x4 *slot = lds[wv][h];
-  uint32_t b[U], o[U];
+  uint32_t b[U];
+  int64_t o[U];
   u32x4 ld[U];
   uintptr_t first_payload;
   uint32_t mb;
   // widths and offsets of the wave's 2 * U consecutive blocks: one coalesced load per array (blocks past the end
   // repeat the last one), handed to the half-waves through the LDS crossbar (a ds_bpermute costs one instruction
-  // where the scalar hand-out of the decoders costs four).  The offsets travel as 32-bit distances from the wave's
-  // first block (16 blocks span at most 8 KiB)
+  // where the scalar hand-out of the decoders costs four).  The offsets travel as signed 32-bit distances from the
+  // wave's first block: with offsets from a scan 16 blocks span at most 8 KiB, and any arrangement of the payloads
+  // within 2 GiB either side works the same; when a block of the wave lies further away (payload offsets may be any
+  // multiples of 16) the high halves travel too.
   constexpr int NB = 2 * U;
   const size_t wb = (tile * 4 + wv) * NB;
   if (wb >= nblocks) return;  // (whole waves; no workgroup barrier below)
@@ -78,18 +82,30 @@ __global__ __launch_bounds__(256) void k_block_sums(const uint8_t *payload, cons
     const uint64_t mo0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(mo >> 32)) << 32) |
                          (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)mo);
     first_payload = reinterpret_cast<uintptr_t>(payload) + mo0;
-    const uint32_t rel = (uint32_t)(mo - mo0);
+    const int64_t dist = (int64_t)(mo - mo0);
+    const uint32_t rel = (uint32_t)dist;
+    const bool far = dist != (int64_t)(int32_t)rel;
+    const bool any_far = __builtin_amdgcn_ballot_w64(far) != 0;  // wave-uniform; no load sits behind this branch
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int from = 4 * (2 * u + h);  // byte address of the source lane
       b[u] = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)mb);
-      o[u] = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)rel);
+      o[u] = (int64_t)(int32_t)__builtin_amdgcn_ds_bpermute(from, (int)rel);
+    }
+    if (any_far) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * (2 * u + h), (int)(uint32_t)((uint64_t)dist >> 32));
+        o[u] = (int64_t)(((uint64_t)hi << 32) | (uint32_t)o[u]);
+      }
     }
   }
-  const uintptr_t zeros = reinterpret_cast<uintptr_t>(&g_nothing);
+  // lanes past a payload's end must contribute zeros (the sums below rely on it): they load sixteen zero bytes from
+  // read-only memory of this kernel's own (not the scratch vector other kernels use as a dummy load target)
+  const uintptr_t zeros = reinterpret_cast<uintptr_t>(&g_sixteen_zero_bytes);
 #pragma unroll
   for (int u = 0; u < U; ++u)
-    ld[u] = load_global_at((uint32_t)k < b[u] ? first_payload + (o[u] + 16 * (uint32_t)k) : zeros);
+    ld[u] = load_global_at((uint32_t)k < b[u] ? first_payload + (uintptr_t)(o[u] + 16 * (int64_t)k) : zeros);
   const bool edge = k == 0 || k == 31;
   uint32_t *mine_out = &gathered[wv][k & 1][h];
 #pragma unroll

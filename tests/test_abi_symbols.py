@@ -47,6 +47,34 @@ def test_library_exports_nothing_else():
     assert exported == declared, (sorted(set(exported) - set(declared)), sorted(set(declared) - set(exported)))
 
 
+def test_soname_and_binary_substitution_resolve(tmp_path):
+    """The library carries a soname, and a program that was compiled against the REFERENCE's headers and linked to the
+    REFERENCE's own shared library (oracle/_ref/example_reflinked: NEEDED libsimdcomp.so, nothing of this repository
+    in it) resolves every symbol against this library when libsimdcomp.so is a link to it: the dynamic loader's own
+    trace (no code of the program runs, so no GPU is needed).  With the reference's library in its place the same
+    binary runs here on the CPU and passes its own checks."""
+    import subprocess
+
+    dyn = subprocess.run(["readelf", "-d", binding.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "libsimdcomp_hip.so.0" in dyn and "SONAME" in dyn
+    exe = os.path.join(ROOT, "oracle", "_ref", "example_reflinked")
+    reflib = os.path.join(ROOT, "oracle", "_ref", "reflib")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/example_reflinked was not built (needs the reference tree at build time)")
+    needed = subprocess.run(["readelf", "-d", exe], capture_output=True, text=True, check=True).stdout
+    assert "libsimdcomp.so" in needed and "simdcomp_hip" not in needed
+    os.symlink(os.path.abspath(binding.LIB_PATH), tmp_path / "libsimdcomp.so")
+    env = dict(os.environ, LD_LIBRARY_PATH=f"{tmp_path}:/opt/rocm/lib", LD_TRACE_LOADED_OBJECTS="1", LD_BIND_NOW="1", LD_WARN="1")
+    out = subprocess.run([exe], capture_output=True, text=True, env=env)
+    text = out.stdout + out.stderr
+    assert f"libsimdcomp.so => {tmp_path}/libsimdcomp.so" in text, text
+    assert "libamdhip64" in text and "undefined symbol" not in text and "not found" not in text, text
+    # the control: the same binary on the library it was linked to
+    env = dict(os.environ, LD_LIBRARY_PATH=reflib)
+    out = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=120)
+    assert out.returncode == 0 and out.stdout.count("Code works!") >= 2, out.stdout[-1000:] + out.stderr[-1000:]
+
+
 def test_version_and_sizes(orc):
     lib = binding.lib()
     assert lib.simdcomp_hip_version() >= 100
@@ -113,7 +141,10 @@ def test_single_value_accessors(orc, bit):
     for key in list(xf[::9]) + [0, base, int(xf[-1]) + 1, 0xFFFFFFFF]:
         for length in (128, 77, 1):
             pos = lib.simdsearchwithlengthFOR(base, comp.ctypes.data, bit, length, int(key), C.byref(res))
-            assert (pos, res.value) == orc.simdsearchwithlengthFOR(base, comp, bit, length, int(key))
+            wpos, wval = orc.simdsearchwithlengthFOR(base, comp, bit, length, int(key))
+            if wpos == 128 and bit:
+                wval = 0  # the reference reads past the block there (the restatement reads the padding); the library does not
+            assert (pos, res.value) == (wpos, wval)
     newv = synth.random_bits(12, 128, bit)
     mine, want = comp.copy(), comp[: 16 * bit].copy()
     for idx in (0, 1, 5, 31, 64, 126, 127):

@@ -161,9 +161,10 @@ def test_lengths(lib, orc, bit):
 
 
 def test_long_array_crosses_pipeline_pieces(lib, orc):
-    """More than one 2^24-integer staging piece, ragged end, arbitrary 32-bit data
-    (so the frame packer's hand-over between blocks is exercised across the piece cut)."""
-    n = (1 << 24) + (1 << 18) + 77
+    """More 2^24-integer pieces than the pipeline has staging slots (so slots are reused while uploads, kernels and
+    downloads of neighbouring pieces are in flight), ragged end, arbitrary 32-bit data (so the frame packer's
+    hand-over between blocks is exercised across the piece cuts)."""
+    n = 3 * (1 << 24) + (1 << 18) + 77
     x = synth.rand_u32(9, n)
     for bit in (5, 32):
         nbytes = lib.simdpack_compressedbytes(n, bit)
@@ -181,6 +182,45 @@ def test_long_array_crosses_pipeline_pieces(lib, orc):
         assert orc.fnv1a64(buf[:nbytes]) == orc.fnv1a64(orc.simdpack_length(x, bit))
     assert lib.maxbits_length(p(x), n) == 32
     assert lib.simdmaxbitsd1_length(0, p(x), n) == 32
+
+
+def test_long_arrays_in_pinned_memory_are_coded_in_place(lib, orc):
+    """Caller buffers in pinned host memory take the path without staging (the kernels read and write them over the
+    host link): same bytes as the staged path, nothing written past the end; a pinned buffer at an address that is not
+    16-byte aligned, or only one pinned side, goes through staging and gives the same bytes again."""
+    import torch
+
+    n = (1 << 22) + 77
+    x = synth.rand_u32(19, n)
+    hx = torch.empty(n + 4, dtype=torch.int32, pin_memory=True)
+    hx[:n] = torch.from_numpy(x.view(np.int32))
+    for bit in (7, 32):
+        nbytes = lib.simdpack_compressedbytes(n, bit)
+        want = orc.simdpackFOR_length(777, x, bit)
+        wdec, _ = orc.simdunpackFOR_length(777, want, n, bit)
+        hbuf = torch.full((nbytes + 64,), 0xA5, dtype=torch.uint8, pin_memory=True)
+        hout = torch.full((n + 8,), 0x5A5A5A5A, dtype=torch.int32, pin_memory=True)
+        for shift in (0, 4):  # 0: in place; 4: the payload is not 16-byte aligned -> staged
+            hbuf.fill_(0xA5)
+            end = lib.simdpackFOR_length(777, hx.data_ptr(), n, hbuf.data_ptr() + shift, bit)
+            assert end - (hbuf.data_ptr() + shift) == nbytes
+            got = hbuf.numpy()
+            assert np.array_equal(got[shift:shift + nbytes], want), (bit, shift)
+            assert (got[:shift] == 0xA5).all() and (got[shift + nbytes:] == 0xA5).all(), "wrote outside the payload"
+            hout.fill_(0x5A5A5A5A)
+            lib.simdunpackFOR_length(777, hbuf.data_ptr() + shift, n, hout.data_ptr(), bit)
+            assert np.array_equal(hout.numpy()[:n].view(np.uint32), wdec), (bit, shift)
+            assert (hout[n:] == 0x5A5A5A5A).all()
+        # plain coding, pinned input and pageable output
+        buf = np.zeros(nbytes + 16, np.uint8)
+        end = lib.simdpack_length(hx.data_ptr(), n, p(buf), bit)
+        assert end - p(buf) == nbytes and np.array_equal(buf[:nbytes], orc.simdpack_length(x, bit))
+        out = np.zeros(n, np.uint32)
+        hbuf[:nbytes] = torch.from_numpy(buf[:nbytes])
+        lib.simdunpack_length(hbuf.data_ptr(), n, p(out), bit)
+        assert np.array_equal(out, x if bit == 32 else x & np.uint32((1 << bit) - 1))
+        lib.simdunpack_length(hbuf.data_ptr(), n, hout.data_ptr(), bit)
+        assert np.array_equal(hout.numpy()[:n].view(np.uint32), out)
 
 
 def test_device_checksum_matches_host_formula():

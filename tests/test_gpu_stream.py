@@ -136,6 +136,42 @@ def test_stream_sizes_and_alignments(dev, orc, nblk):
         assert np.array_equal(u32(out), orc.stream_decode(want, nblk, d1=True, initvalue=init))
 
 
+@pytest.mark.parametrize("layout", ["reversed", "padded", "far"])
+def test_chain_offsets_with_any_payload_offsets(dev, orc, layout):
+    """Payload offsets need not come from a scan: any multiples of 16 are legal for pack_mixed / unpack_mixed, so
+    chain_offsets must take them too -- blocks laid out back to front (negative distances inside a wave), padded
+    apart, and more than 4 GiB apart (distances that do not fit 32 bits)."""
+    import torch
+
+    nblk = 1000 + 7
+    x = G.stream_corpus(321, nblk)
+    d_x = to_dev(x)
+    seeds = torch.empty(nblk, dtype=torch.int32, device="cuda")
+    bits = dev.maxbitsd1(d_x, initvalue=0, initvalues_out=seeds)
+    scan, total = dev.payload_offsets(bits)
+    nbytes = int(total.item())
+    size = 16 * bits.to(torch.int64)
+    if layout == "reversed":
+        off = nbytes - scan - size  # block 0 last
+        span = nbytes
+    elif layout == "padded":
+        off = scan + 48 * torch.arange(nblk, device="cuda")
+        span = nbytes + 48 * nblk
+    else:
+        if torch.cuda.mem_get_info()[0] < 12 * (1 << 30):
+            pytest.skip("needs 10 GiB of free HBM")
+        far = (torch.arange(nblk, device="cuda") % 3 == 1).to(torch.int64) * (5 << 30)  # every third block 5 GiB up
+        off = scan + far
+        span = nbytes + (5 << 30)
+    arena = torch.empty(span + 16, dtype=torch.uint8, device="cuda")
+    dev.pack_mixed(D1, d_x, bits, off, arena, initvalues=seeds)
+    chained = dev.chain_offsets(arena, bits, off, initvalue=0)
+    assert np.array_equal(u32(chained), u32(seeds))
+    out = dev.unpack_mixed(D1, arena, bits, off, nblk, initvalues=chained)
+    assert np.array_equal(u32(out), x)
+    del arena
+
+
 def test_index_rejects_bad_streams(dev, orc):
     x = G.stream_corpus(77, 3000)
     s = orc.stream_compress(x, d1=True)
