@@ -90,5 +90,6 @@ def test_two_ranks_share_one_gpu():
     assert md["shards_contiguous"] and md["widths_match_description"] and md["blocks_covered"] == md["total_blocks"]
     assert md["per_rank"][0]["blocks"] > md["per_rank"][1]["blocks"]  # equal bytes, not equal block counts
     assert md["imbalance"]["cost_bytes_max_over_mean"] < 1.001
-    assert doc["host_to_host"]["ranks"] == 2 and doc["host_to_host"]["per_width"]["mixed"]["round_trip_ok"]
+    mixed = doc["host_to_host"]["per_width"]["mixed"]
+    assert doc["host_to_host"]["ranks"] == 2 and mixed["round_trip_ok"] and mixed["staged_round_trip_ok"]
     assert doc["cpu_baseline"]["decode_vs_gpu_mismatches"] == 0 and doc["cpu_baseline"]["value"] > 0

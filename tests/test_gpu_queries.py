@@ -93,12 +93,22 @@ def mixed_corpus(dev, nblk, seed):
     return x, seeds, bits, off, arena, stream
 
 
-def test_batched_queries_mixed_widths(dev, orc):
-    """Random (block, key) and (block, slot) queries over a mixed-width d1 corpus, both layouts."""
+@pytest.mark.parametrize("order", ["random", "sorted", "hot", "descending"])
+def test_batched_queries_mixed_widths(dev, orc, order):
+    """(block, key) and (block, slot) queries over a mixed-width d1 corpus, both layouts: a random block per query;
+    the same batch sorted by block (neighbouring queries on one block share its decode: runs of every length,
+    across the 64-query groups the kernel works in); a batch on a handful of blocks (runs far longer than a group);
+    and sorted downwards (runs, but no ascending order to lean on)."""
     nblk, nq = 3000, 20011
     x, seeds, bits, off, arena, stream = mixed_corpus(dev, nblk, 61)
     h_bits, h_off, h_seeds, h_arena = bits.cpu().numpy(), off.cpu().numpy(), u32(seeds), arena.cpu().numpy()
     qb = (synth.rand_u32(1, nq) % np.uint32(nblk)).astype(np.uint64)
+    if order == "hot":
+        qb = (qb % np.uint64(37)) * np.uint64(81)
+    if order != "random":
+        qb = np.sort(qb)
+    if order == "descending":
+        qb = qb[::-1].copy()
     slots = (synth.rand_u32(2, nq) % np.uint32(256)).astype(np.int32)
     lengths = (synth.rand_u32(3, nq) % np.uint32(129)).astype(np.int32)
     raw = h_bits[qb.astype(np.int64)] == 32

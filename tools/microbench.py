@@ -168,8 +168,12 @@ def query(n, nblk, reps):
     arena = torch.empty(T + 16, dtype=torch.uint8, device=dev)
     codec.pack_mixed(1, ids, bits, off, arena, initvalues=seeds)
     res = {"blocks": nblk, "avg_bits": round(T / nblk / 16, 2)}
-    for name, nq, qb in (("random_blocks", 1 << 24, torch.randint(0, nblk, (1 << 24,), device=dev)),
-                         ("every_block", nblk, None)):
+    rnd = torch.randint(0, nblk, (1 << 24,), device=dev)
+    # "sorted_blocks": the same random batch in block order, what an intersection of posting lists issues (two
+    # queries per block on average here); "hot_blocks": sorted, sixteen queries per block
+    hot = torch.sort(torch.randint(0, nblk // 16, (1 << 24,), device=dev) * 16)[0]
+    for name, nq, qb in (("random_blocks", 1 << 24, rnd), ("sorted_blocks", 1 << 24, torch.sort(rnd)[0]),
+                         ("hot_blocks", 1 << 24, hot), ("every_block", nblk, None)):
         blk = qb if qb is not None else torch.arange(nblk, device=dev)
         keys = ids.view(-1, 128)[blk, torch.randint(0, 128, (nq,), device=dev)] + 1
         slots = torch.randint(0, 128, (nq,), dtype=torch.int32, device=dev)

@@ -7,10 +7,10 @@ set -e
 cd "$(dirname "$0")/../simdcomp_amd/csrc"
 NAME=$1; FILE=$2; DEFS=$3
 mkdir -p ../variants build
-make -s build/exports.map $(for f in codec_kernels stream_kernels query_kernels device_api host_api scalar_access; do echo build/$f.o; done)
+make -s build/exports.map $(for f in codec_kernels stream_kernels query_kernels device_api host_api scalar_access host_arith; do echo build/$f.o; done)
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -DSIMDCOMP_HIP_BUILDING $DEFS --offload-arch=gfx950 -c $FILE.hip -o ../variants/$NAME.o
 OBJS=""
-for f in codec_kernels stream_kernels query_kernels device_api host_api scalar_access; do
+for f in codec_kernels stream_kernels query_kernels device_api host_api scalar_access host_arith; do
   if [ "$f" = "$FILE" ]; then OBJS="$OBJS ../variants/$NAME.o"; else OBJS="$OBJS build/$f.o"; fi
 done
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -Wl,--version-script=build/exports.map -o ../variants/lib$NAME.so $OBJS
