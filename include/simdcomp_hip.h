@@ -56,6 +56,11 @@ const char *simdcomp_hip_last_error(void);
  * stderr and aborts.  A program may install a handler instead; it receives the
  * message and `arg` and must not return (longjmp, exit, or throw through C++
  * frames); if it does return the library aborts.  NULL restores the default.
+ * Before the handler runs the device is drained, so no copy of the failed call
+ * is still writing into the caller's buffers (their contents are unspecified).
+ * After a handler has left through longjmp the calling thread's current HIP
+ * device may be the one the call ran on (SIMDCOMP_HIP_DEVICES) rather than the
+ * caller's; set it again before other HIP work.  The library stays usable.
  * The batched entry points below never call it: they return error codes. */
 typedef void (*simdcomp_hip_error_handler)(const char *message, void *arg);
 void simdcomp_hip_set_error_handler(simdcomp_hip_error_handler handler, void *arg);

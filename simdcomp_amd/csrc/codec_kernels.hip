@@ -1268,7 +1268,9 @@ constexpr int pack_threads(int b) { return (b >= SC_PW_LO && b <= SC_PW_HI) ? SC
 constexpr int pack_steps(int b) { return (b >= SC_PW_LO && b <= SC_PW_HI) ? SC_PW_U : (b < 0 ? SC_PM_U : (pack_narrow_shape(b) ? (b >= 4 ? SC_PN_U : 2) : 1)); }
 
 // (16-lane layout: 128 threads at every width; 256 from 20 bits on, as the 4-lane layout has them, ran at 72.5 %
-// against 75-76 % at 24 and 32 bits)
+// against 75-76 % at 24 and 32 bits.  A decoder with k_pack16's lane mapping -- whole wide blocks per wave, the payload
+// fetched by one or two fully coalesced loads, groups taken apart in LDS -- was built and measured: 76-77 % at 24..32
+// bits, 70-74 % below 16 bits where this kernel has its prefetch workgroups and runs at 78-83 %: not kept.)
 #ifndef SC_U16_BS
 #define SC_U16_BS 128
 #endif
@@ -1362,6 +1364,122 @@ hipError_t launch_unpack(int mode, bool tail, const UnpackArgs &a, hipStream_t s
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------
+// The 16-lane layout's own encoder (avx512pack / avx512packwithoutmask, src/avx512bitpacking.c): a wave takes whole
+// wide blocks of 512 integers.  Lane 16 g + r holds rows r and r + 16 of lane group g (integers 16 R + 4 g .. + 3 of
+// the block for row R), so that one load instruction of the wave reads 16 rows x 64 bytes = 1 KiB in one piece (with
+// one four-lane group per half-wave, as k_pack_fast maps it, an instruction touches 32 bytes of every 64-byte line
+// and each line is fetched by two instructions: 71-78 % of the HBM peak where the 8-lane layout, whose two groups
+// do fill a line, reaches 80-84 %).  A lane group's rows 0..15 and 16..31 each sit in one DPP row of 16 lanes: the
+// hand-over of spilled bits and the segmented OR-scan over the rows that share an output word use row shifts inside
+// the two halves and a row rotation from the first half into the second (row 15 -> row 16 and on).  The four groups'
+// vectors of one output word are 64 contiguous bytes, stored by one instruction.
+// ---------------------------------------------------------------------------
+constexpr int DPP_ROW_ROR1 = 0x121, DPP_ROW_ROR2 = 0x122, DPP_ROW_ROR4 = 0x124, DPP_ROW_ROR8 = 0x128;
+#ifndef SC_P16_BS
+#define SC_P16_BS 128
+#endif
+#ifndef SC_P16_U
+#define SC_P16_U 1
+#endif
+#ifndef SC_P16
+#define SC_P16 1
+#endif
+
+template <int B, bool MASKED, int U, int BS>
+__global__ __launch_bounds__(BS) void k_pack16(PackArgs a) {
+  static_assert(B >= 1 && B <= 32, "widths 1..32");
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t g = (uint32_t)lane >> 4, r = (uint32_t)lane & 15;
+  const u32x4 *in = reinterpret_cast<const u32x4 *>(a.in);
+  u32x4 *payload = reinterpret_cast<u32x4 *>(a.payload);
+  const size_t first = ((size_t)blockIdx.x * (BS / 64) + (size_t)wv) * U;
+  u32x4 x0[U], x1[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const u32x4 *blk = in + (first + u) * 128 + 4 * r + g;
+    x0[u] = __builtin_nontemporal_load(blk);
+    x1[u] = __builtin_nontemporal_load(blk + 64);
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    u32x4 *out = payload + (first + u) * (size_t)(4 * B) + g;  // vector w of this group at out + 4 w
+    if constexpr (B == 32) {
+      __builtin_nontemporal_store(x0[u], out + 4 * r);
+      __builtin_nontemporal_store(x1[u], out + 4 * (r + 16));
+    } else {
+      u32x4 v0 = x0[u], v1 = x1[u];
+      if constexpr (MASKED) {
+        v0 &= field_mask(B);
+        v1 &= field_mask(B);
+      }
+      const uint32_t p0 = r * B, w0 = p0 >> 5, s0 = p0 & 31;
+      const uint32_t p1 = (r + 16) * B, w1 = p1 >> 5, s1 = p1 & 31;
+      u32x4 t0 = v0 << s0, t1 = v1 << s1;
+      // bits that do not fit the row's first word go to the next row's word (which is where that row starts)
+      const u32x4 sp0 = (v0 >> ((32 - s0) & 31)) & (s0 + B > 32 ? 0xFFFFFFFFu : 0u);
+      const u32x4 sp1 = (v1 >> ((32 - s1) & 31)) & (s1 + B > 32 ? 0xFFFFFFFFu : 0u);
+      const u32x4 sp0_last = sp0 & (r == 15 ? 0xFFFFFFFFu : 0u);  // row 15 hands over to row 16
+      t0.x |= dpp0<DPP_ROW_SHR1>(sp0.x);
+      t0.y |= dpp0<DPP_ROW_SHR1>(sp0.y);
+      t0.z |= dpp0<DPP_ROW_SHR1>(sp0.z);
+      t0.w |= dpp0<DPP_ROW_SHR1>(sp0.w);
+      t1.x |= dpp0<DPP_ROW_SHR1>(sp1.x) | dpp0<DPP_ROW_ROR1>(sp0_last.x);
+      t1.y |= dpp0<DPP_ROW_SHR1>(sp1.y) | dpp0<DPP_ROW_ROR1>(sp0_last.y);
+      t1.z |= dpp0<DPP_ROW_SHR1>(sp1.z) | dpp0<DPP_ROW_ROR1>(sp0_last.z);
+      t1.w |= dpp0<DPP_ROW_SHR1>(sp1.w) | dpp0<DPP_ROW_ROR1>(sp0_last.w);
+      // Segmented inclusive OR-scan over the rows that start in the same word.  Row R hands its partial word to row
+      // R + D when that row starts in the same word, i.e. D * B <= bit offset of row R + D (masked at the giving
+      // lane, so that the taker's OR folds the DPP move in).  Rows 16 - D .. 15 give to the second half (rotation).
+#define SC_P16_STEP(D, SHR, ROR)                                                                            \
+  if constexpr (D < max_rows_per_word(B)) {                                                                 \
+    const uint32_t give0 = ((uint32_t)D * B <= (((r + D) * B) & 31u)) ? 0xFFFFFFFFu : 0u;                    \
+    const uint32_t give1 = ((uint32_t)D * B <= (((r + 16 + D) * B) & 31u)) ? 0xFFFFFFFFu : 0u;               \
+    const uint32_t wrap = (r >= 16 - D) ? give0 : 0u;                                                       \
+    const u32x4 n1 = {t1.x | dpp0<SHR>(t1.x & give1) | dpp0<ROR>(t0.x & wrap), t1.y | dpp0<SHR>(t1.y & give1) | dpp0<ROR>(t0.y & wrap), \
+                      t1.z | dpp0<SHR>(t1.z & give1) | dpp0<ROR>(t0.z & wrap), t1.w | dpp0<SHR>(t1.w & give1) | dpp0<ROR>(t0.w & wrap)}; \
+    t0.x |= dpp0<SHR>(t0.x & give0);                                                                         \
+    t0.y |= dpp0<SHR>(t0.y & give0);                                                                         \
+    t0.z |= dpp0<SHR>(t0.z & give0);                                                                         \
+    t0.w |= dpp0<SHR>(t0.w & give0);                                                                         \
+    t1 = n1;                                                                                                \
+  }
+      SC_P16_STEP(1, DPP_ROW_SHR1, DPP_ROW_ROR1)
+      SC_P16_STEP(2, DPP_ROW_SHR2, DPP_ROW_ROR2)
+      SC_P16_STEP(4, DPP_ROW_SHR4, DPP_ROW_ROR4)
+      SC_P16_STEP(8, DPP_ROW_SHR8, DPP_ROW_ROR8)
+#undef SC_P16_STEP
+      if constexpr (16 < max_rows_per_word(B)) t1 |= t0;  // one bit per value: all 32 rows share word 0
+      // the last row of a word holds it whole
+      const bool last0 = (((r + 1) * B) >> 5) != w0;
+      const bool last1 = r == 15 || (((r + 17) * B) >> 5) != w1;
+      if (last0) __builtin_nontemporal_store(t0, out + 4 * w0);
+      if (last1) __builtin_nontemporal_store(t1, out + 4 * w1);
+    }
+  }
+}
+
+// -> blocks done, in four-lane blocks (four per wide block)
+template <bool MASKED, int BP1>
+static size_t launch_pack16(const PackArgs &a, hipStream_t st) {
+  constexpr int B = BP1 - 1;
+  if constexpr (B < 1) {
+    return 0;
+  } else {
+    constexpr size_t per_wg = (size_t)(SC_P16_BS / 64) * SC_P16_U;  // wide blocks per workgroup
+    const size_t nwg = (a.nblocks / 4) / per_wg;
+    if (nwg) hipLaunchKernelGGL((k_pack16<B, MASKED, SC_P16_U, SC_P16_BS>), dim3((unsigned)nwg), dim3(SC_P16_BS), 0, st, a);
+    return nwg * per_wg * 4;
+  }
+}
+
+template <bool MASKED, int... Is>
+static size_t dispatch_pack16(int bit, const PackArgs &a, hipStream_t st, std::integer_sequence<int, Is...>) {
+  using fn_t = size_t (*)(const PackArgs &, hipStream_t);
+  static const fn_t table[] = {&launch_pack16<MASKED, Is + 1>...};
+  return table[bit](a, st);
+}
+
 template <int MODE, bool MASKED, int BP1, int LS = 0, bool GENERIC = false>
 static size_t launch_pack_fast(const PackArgs &a, hipStream_t st) {
   constexpr int U = pack_steps(BP1 - 1), BS = pack_threads(BP1 - 1);
@@ -1453,6 +1571,7 @@ hipError_t launch_pack(int mode, bool masked, bool generic, const PackArgs &a, h
     size_t done;
     if (wide) {
       if (a.lane_groups == 2) done = masked ? dispatch_pack_wide<true, 1>((int)a.bit, c, st, wseq{}) : dispatch_pack_wide<false, 1>((int)a.bit, c, st, wseq{});
+      else if (SC_P16 && a.bit >= 1) done = masked ? dispatch_pack16<true>((int)a.bit, c, st, wseq{}) : dispatch_pack16<false>((int)a.bit, c, st, wseq{});
       else done = masked ? dispatch_pack_wide<true, 2>((int)a.bit, c, st, wseq{}) : dispatch_pack_wide<false, 2>((int)a.bit, c, st, wseq{});
     } else if (mode == MODE_PLAIN) {
       done = masked ? dispatch_pack_fast<MODE_PLAIN, true>(idx, c, st, seq{})

@@ -41,7 +41,13 @@ std::atomic<void *> g_handler_arg{nullptr};
 [[noreturn]] void die(const char *where, const char *what) {
   char msg[320];
   snprintf(msg, sizeof msg, "simdcomp_hip: %s failed: %s", where, what);
-  if (simdcomp_hip_error_handler h = g_handler.load()) h(msg, g_handler_arg.load());
+  if (simdcomp_hip_error_handler h = g_handler.load()) {
+    // the handler may leave through longjmp: nothing of this call may still be writing into the caller's buffers
+    // then (copies of the piece pipeline that are in flight), so the device is drained first; errors are ignored
+    (void)hipDeviceSynchronize();
+    (void)hipGetLastError();
+    h(msg, g_handler_arg.load());
+  }
   fprintf(stderr, "%s\n", msg);
   abort();
 }

@@ -79,6 +79,14 @@ def test_gpu_lanes(orc, lanes):
         assert np.array_equal(got[:nblk * n], x) and (got[nblk * n:] == 0x5A5A5A5A).all()
         assert np.array_equal(codec.maxbits_lanes(lanes, to_dev(x)).cpu().numpy(),
                               np.array([orc.lanes_maxbits(lanes, x[k * n:(k + 1) * n]) for k in range(nblk)], np.uint8))
+        # arbitrary 32-bit input through the many-block kernels: masked, and unmasked (out-of-range bits land in the
+        # neighbouring fields exactly as in the reference)
+        if bit:
+            wild = synth.rand_u32(1400 + bit, nblk * n)
+            for masked in (True, False):
+                want = np.concatenate([orc.lanes_pack(lanes, wild[k * n:(k + 1) * n], bit, masked) for k in range(nblk)])
+                got = codec.pack_lanes(lanes, to_dev(wild), bit, masked=masked).cpu().numpy()
+                assert np.array_equal(got, want), (lanes, bit, masked)
 
 
 @pytest.mark.gpu

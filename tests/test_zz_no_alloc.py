@@ -49,3 +49,35 @@ def test_noalloc_rejects_sizes_beyond_its_scratch():
     assert rc == -5 and b"max_blocks" in L.simdcomp_hip_last_error()
     assert L.simdcomp_hip_payload_offsets_noalloc(None, 0, None, None, None) == 0  # nothing to do, nothing touched
     torch.cuda.synchronize()
+
+
+def test_noalloc_call_captured_in_a_graph_and_replayed():
+    """What the entry point is for: captured in a HIP graph (after one plain call on the device, which resolves the
+    address of the library's scratch array -- that look-up is not capturable), then replayed on new widths in the same
+    buffers.  Capture fails on any allocation, so passing also shows that the call makes none."""
+    L = B.lib()
+    dev = torch.device("cuda", 0)
+    nblk = 4096 * 7 + 123
+    bits = torch.from_numpy(synth.skewed_widths(11, nblk, 0, 32)).to(dev)
+    off = torch.zeros(nblk, dtype=torch.int64, device=dev)
+    total = torch.zeros(1, dtype=torch.int64, device=dev)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        B.check(L.simdcomp_hip_payload_offsets_noalloc(B.ptr(bits), nblk, B.ptr(off), B.ptr(total), side.cuda_stream), "warm-up")
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        st = torch.cuda.current_stream().cuda_stream
+        B.check(L.simdcomp_hip_payload_offsets_noalloc(B.ptr(bits), nblk, B.ptr(off), B.ptr(total), st), "captured")
+    for seed in (12, 13):
+        w = synth.skewed_widths(seed, nblk, 0, 32)
+        bits.copy_(torch.from_numpy(w).to(dev))
+        off.fill_(-1)
+        total.fill_(-1)
+        g.replay()
+        torch.cuda.synchronize()
+        want = np.concatenate([[0], np.cumsum(w.astype(np.uint64) * 16)])
+        assert int(total[0]) == int(want[-1])
+        assert np.array_equal(off.cpu().numpy().astype(np.uint64), want[:-1])
