@@ -810,6 +810,7 @@ __device__ __forceinline__ u32x4 reduce_load(const u32x4 *p) {
 
 template <int WHAT, int U>
 __global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
+  __shared__ uint32_t minmax_rows[WHAT == RED_MINMAX ? 2 : 1][WHAT == RED_MINMAX ? 4 : 1][2][WHAT == RED_MINMAX ? U : 1][32];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int h = lane >> 5, k = lane & 31;
   const size_t per_iter = (size_t)BLOCKS_PER_STEP * U;
@@ -819,7 +820,7 @@ __global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
     u32x4 x[U];
     uint32_t seed[U];
     bool valid[U];
-    uint32_t out_bits = 0, out_seed = 0, out_min = 0, out_max = 0;
+    uint32_t out_bits = 0, out_seed = 0;
     // every load is issued unconditionally (a block past the end re-reads the last one; only the stores are
     // predicated), and the U loads of a kind back to back: behind a per-step branch they would wait for one another
     size_t bc[U];
@@ -867,24 +868,10 @@ __global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if constexpr (WHAT == RED_MINMAX) {
-        uint32_t lo = min(min(x[u].x, x[u].y), min(x[u].z, x[u].w));
-        uint32_t hi = max(max(x[u].x, x[u].y), max(x[u].z, x[u].w));
-        // min / max into lane 31 of the half-wave (a lane with no source keeps its own value), then gathered like
-        // the widths below: one store per array and wave instead of one per block
-        lo = min(lo, dpp_keep<DPP_ROW_SHR1>(lo));
-        hi = max(hi, dpp_keep<DPP_ROW_SHR1>(hi));
-        lo = min(lo, dpp_keep<DPP_ROW_SHR2>(lo));
-        hi = max(hi, dpp_keep<DPP_ROW_SHR2>(hi));
-        lo = min(lo, dpp_keep<DPP_ROW_SHR4>(lo));
-        hi = max(hi, dpp_keep<DPP_ROW_SHR4>(hi));
-        lo = min(lo, dpp_keep<DPP_ROW_SHR8>(lo));
-        hi = max(hi, dpp_keep<DPP_ROW_SHR8>(hi));
-        lo = min(lo, dpp_keep<DPP_ROW_BCAST15, 0xA>(lo));
-        hi = max(hi, dpp_keep<DPP_ROW_BCAST15, 0xA>(hi));
-        const uint32_t lo0 = (uint32_t)__builtin_amdgcn_readlane((int)lo, 31), lo1 = (uint32_t)__builtin_amdgcn_readlane((int)lo, 63);
-        const uint32_t hi0 = (uint32_t)__builtin_amdgcn_readlane((int)hi, 31), hi1 = (uint32_t)__builtin_amdgcn_readlane((int)hi, 63);
-        out_min = lane == 2 * u ? lo0 : (lane == 2 * u + 1 ? lo1 : out_min);
-        out_max = lane == 2 * u ? hi0 : (lane == 2 * u + 1 ? hi1 : out_max);
+        // every row's minimum and maximum go to LDS, [half-wave][step][row]; the reduction over the rows follows
+        // the loop, for all of the wave's blocks at once
+        minmax_rows[0][wv][h][u][k] = min(min(x[u].x, x[u].y), min(x[u].z, x[u].w));
+        minmax_rows[1][wv][h][u][k] = max(max(x[u].x, x[u].y), max(x[u].z, x[u].w));
       } else {
         u32x4 v = x[u];
         if constexpr (WHAT == RED_MAXBITSD1) {
@@ -910,14 +897,37 @@ __global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
         }
       }
     }
-    {
+    if constexpr (WHAT == RED_MINMAX) {
+      // 64 / (2 U) lanes per block: each takes the minimum and maximum of 32 / that many consecutive rows (one
+      // 16-byte LDS read per array), then the lanes of a block combine through DPP moves that stay inside their group
+      // of eight (neighbour, other pair, other quad).  A reduction per block and array across 32 lanes -- five DPP
+      // steps each, with a register copy per step because min and max have no neutral fill value -- cost this
+      // kernel 8 points of HBM peak against the OR-reductions of the width kernels.
+      static_assert(U == 4, "eight lanes per block, four rows per lane");
+      wave_lds_fence();
+      const int i = lane >> 3, part = lane & 7;  // block 2 * uu + hh of the wave
+      const int hh = i / U, uu = i % U;
+      const u32x4 l4 = *reinterpret_cast<const u32x4 *>(&minmax_rows[0][wv][hh][uu][4 * part]);
+      const u32x4 h4 = *reinterpret_cast<const u32x4 *>(&minmax_rows[1][wv][hh][uu][4 * part]);
+      uint32_t lo = min(min(l4.x, l4.y), min(l4.z, l4.w));
+      uint32_t hi = max(max(h4.x, h4.y), max(h4.z, h4.w));
+      constexpr int QUAD_SWAP1 = 0xB1, QUAD_SWAP2 = 0x4E, ROW_HALF_MIRROR = 0x141;
+      lo = min(lo, dpp_keep<QUAD_SWAP1>(lo));
+      hi = max(hi, dpp_keep<QUAD_SWAP1>(hi));
+      lo = min(lo, dpp_keep<QUAD_SWAP2>(lo));
+      hi = max(hi, dpp_keep<QUAD_SWAP2>(hi));
+      lo = min(lo, dpp_keep<ROW_HALF_MIRROR>(lo));
+      hi = max(hi, dpp_keep<ROW_HALF_MIRROR>(hi));
+      const size_t mine = tile * per_iter + (size_t)wv * 2 * U + (size_t)(2 * uu + hh);
+      if (part == 0 && mine < a.nblocks) {
+        if (a.min_out) a.min_out[mine] = lo;
+        if (a.max_out) a.max_out[mine] = hi;
+        if (a.bits_out) a.bits_out[mine] = (uint8_t)bits_of(hi - lo);
+      }
+    } else {
       const size_t mine = tile * per_iter + (size_t)wv * 2 * U + (size_t)lane;
       if (lane < 2 * U && mine < a.nblocks) {
-        if constexpr (WHAT == RED_MINMAX) {
-          if (a.min_out) a.min_out[mine] = out_min;
-          if (a.max_out) a.max_out[mine] = out_max;
-          if (a.bits_out) a.bits_out[mine] = (uint8_t)bits_of(out_max - out_min);
-        } else {
+        {
           a.bits_out[mine] = (uint8_t)out_bits;
           if (WHAT == RED_MAXBITSD1 && a.seeds_out) a.seeds_out[mine] = out_seed;
         }

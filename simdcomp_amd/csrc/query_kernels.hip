@@ -214,14 +214,14 @@ __global__ __launch_bounds__(256) void k_query_runs(QueryArgs a) {
   const bool valid = q < a.nqueries;
   const size_t qc = valid ? q : a.nqueries - 1;  // lanes past the end repeat the last query: they join its run
   const uintptr_t nothing = reinterpret_cast<uintptr_t>(&g_nothing);
-  // round 1: the query (block, key or slot, length), one coalesced load per array
+  // first fetch: the query (block, key or slot, length), one coalesced load per array
   const uint64_t qb = load_global_as<uint64_t>(a.query_blocks ? reinterpret_cast<uintptr_t>(a.query_blocks + qc) : nothing);
   const void *ks = WHAT == Q_SELECT ? static_cast<const void *>(a.slots) : static_cast<const void *>(a.keys);
   const uint32_t my_key = load_global_as<uint32_t>(reinterpret_cast<uintptr_t>(ks) + 4 * qc);
   const int ln = load_global_as<int>(WHAT == Q_SEARCH && a.lengths ? reinterpret_cast<uintptr_t>(a.lengths + qc) : nothing);
   const int my_len = a.lengths ? ln : 128;
   const size_t blk = a.query_blocks ? (size_t)qb : qc;
-  // round 2: the block's width, offset and seed (lanes of one run read the same entries: one request)
+  // second fetch: the block's width, offset and seed (lanes of one run read the same entries: one request)
   const uint8_t wb = load_global_as<uint8_t>(a.bits ? reinterpret_cast<uintptr_t>(a.bits + blk) : nothing);
   const uint64_t po = load_global_as<uint64_t>(a.off ? reinterpret_cast<uintptr_t>(a.off + blk) : nothing);
   const uint32_t sd = load_global_as<uint32_t>(MODE != MODE_PLAIN && a.seeds ? reinterpret_cast<uintptr_t>(a.seeds + blk) : nothing);

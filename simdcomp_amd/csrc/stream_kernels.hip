@@ -51,26 +51,35 @@ __constant__ u32x4 g_sixteen_zero_bytes = {0, 0, 0, 0};  // device code cannot w
 constexpr int SUMS_U = SC_SUMS_U;
 constexpr size_t SUMS_PER_WG = 8 * SUMS_U;
 
+// (Measured on 2^23 blocks of 7.5 bits per integer, 0.30 ms: a quarter fewer vector instructions -- the closing
+// reduction below instead of a DPP reduction per block -- changed nothing, and workgroups that touch the payload
+// ahead of the computing ones, as the uniform decoders have them, made it 8 % slower: neither the vector ALU nor the
+// latency of the payload loads bounds this kernel by itself.  Per wave it issues some sixty LDS instructions --
+// hand-over, slot writes, row reads, shares -- next to 205 vector and 11 memory instructions, one dependent chain
+// per step, at eight waves per SIMD.)
 __global__ __launch_bounds__(256) void k_block_sums(const uint8_t *payload, const uint64_t *off, const uint8_t *bits,
                                                     size_t nblocks, uint32_t stream_layout, uint32_t *sums) {
-  __shared__ u32x4 lds[4][2][33];
-  __shared__ uint32_t gathered[4][2][2 * SUMS_U];  // [wave][0: W_0 over the four lane streams, 1: T or last value][block]
   constexpr int U = SUMS_U;
+  const size_t tile = blockIdx.x;
+  static_assert(U == 8, "the closing reduction spreads 2 * U = 16 (half-wave, step) pairs over the 64 lanes, four lanes each");
+  __shared__ u32x4 lds[4][2][33];
+  // every lane's share of each of its blocks, [half-wave][step][row]: summed over the rows at the end, all blocks of
+  // the wave at once (a reduction across the lanes per step costs five dependent DPP additions and their wait states
+  // per block; this way the wave pays seven plain additions and two DPP steps for all sixteen)
+  __shared__ uint32_t shares[4][2][U][32];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int h = lane >> 5, k = lane & 31;
-  const size_t tile = blockIdx.x;
   u32x4 *slot = lds[wv][h];
   uint32_t b[U];
-  int64_t o[U];
+  uintptr_t at[U];
   u32x4 ld[U];
   uintptr_t first_payload;
   uint32_t mb;
   // widths and offsets of the wave's 2 * U consecutive blocks: one coalesced load per array (blocks past the end
   // repeat the last one), handed to the half-waves through the LDS crossbar (a ds_bpermute costs one instruction
-  // where the scalar hand-out of the decoders costs four).  The offsets travel as signed 32-bit distances from the
-  // wave's first block: with offsets from a scan 16 blocks span at most 8 KiB, and any arrangement of the payloads
-  // within 2 GiB either side works the same; when a block of the wave lies further away (payload offsets may be any
-  // multiples of 16) the high halves travel too.
+  // where the scalar hand-out of the decoders costs four).  The offsets travel as 32-bit distances from the wave's
+  // first block (with offsets from a scan 16 blocks span at most 8 KiB); when a block of the wave lies below the
+  // first one or 4 GiB and more above it (payload offsets may be any multiples of 16) the high halves travel too.
   constexpr int NB = 2 * U;
   const size_t wb = (tile * 4 + wv) * NB;
   if (wb >= nblocks) return;  // (whole waves; no workgroup barrier below)
@@ -82,21 +91,24 @@ __global__ __launch_bounds__(256) void k_block_sums(const uint8_t *payload, cons
     const uint64_t mo0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(mo >> 32)) << 32) |
                          (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)mo);
     first_payload = reinterpret_cast<uintptr_t>(payload) + mo0;
-    const int64_t dist = (int64_t)(mo - mo0);
-    const uint32_t rel = (uint32_t)dist;
-    const bool far = dist != (int64_t)(int32_t)rel;
-    const bool any_far = __builtin_amdgcn_ballot_w64(far) != 0;  // wave-uniform; no load sits behind this branch
+    const uint64_t dist = mo - mo0;
+    const uint32_t rel = (uint32_t)dist, rel_hi = (uint32_t)(dist >> 32);
+    const bool any_far = __builtin_amdgcn_ballot_w64(rel_hi != 0) != 0;  // wave-uniform; no load sits behind this branch
+    uint32_t o[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int from = 4 * (2 * u + h);  // byte address of the source lane
       b[u] = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)mb);
-      o[u] = (int64_t)(int32_t)__builtin_amdgcn_ds_bpermute(from, (int)rel);
+      o[u] = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)rel);
     }
-    if (any_far) {
+    if (!any_far) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) at[u] = first_payload + (o[u] + 16 * (uint32_t)k);
+    } else {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * (2 * u + h), (int)(uint32_t)((uint64_t)dist >> 32));
-        o[u] = (int64_t)(((uint64_t)hi << 32) | (uint32_t)o[u]);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * (2 * u + h), (int)rel_hi);
+        at[u] = first_payload + (((uint64_t)hi << 32) | o[u]) + 16 * (uint64_t)k;
       }
     }
   }
@@ -105,25 +117,35 @@ __global__ __launch_bounds__(256) void k_block_sums(const uint8_t *payload, cons
   const uintptr_t zeros = reinterpret_cast<uintptr_t>(&g_sixteen_zero_bytes);
 #pragma unroll
   for (int u = 0; u < U; ++u)
-    ld[u] = load_global_at((uint32_t)k < b[u] ? first_payload + (uintptr_t)(o[u] + 16 * (int64_t)k) : zeros);
-  const bool edge = k == 0 || k == 31;
-  uint32_t *mine_out = &gathered[wv][k & 1][h];
+    ld[u] = load_global_at((uint32_t)k < b[u] ? at[u] : zeros);
+  uint32_t *my_share = &shares[wv][h][0][k];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     wave_lds_fence();
     slot[k] = ld[u];
     wave_lds_fence();
-    const uint32_t p = (uint32_t)k * b[u], w = p >> 5, s = p & 31;
+    const uint32_t p = __umul24((uint32_t)k, b[u]), w = p >> 5, s = p & 31;
     const u32x4 lo = slot[w], hi = slot[w + 1];  // b = 32: s = 0, hi (slot[32] for the last row) is not used
     const uint32_t x = funnel(hi.x, lo.x, s), y = funnel(hi.y, lo.y, s), z = funnel(hi.z, lo.z, s), q = funnel(hi.w, lo.w, s);
-    const uint32_t total = half_scan_add(x + y + z + q);  // lane 0 of the half-wave: W_0 (s = 0, w = 0), lane 31: T
-    // the first and the last lane of each half-wave leave their results in LDS, for one coalesced store at the end
-    if (edge) mine_out[2 * u] = b[u] == 32 ? q : total;
+    // row 0's share is W_0 (s = 0, w = 0); a 32-bit block only needs its last raw value, row 31's q
+    my_share[32 * u] = b[u] == 32 ? q : x + y + z + q;
   }
   wave_lds_fence();
-  if (lane < NB && wb + (size_t)lane < nblocks) {
-    const uint32_t w0 = gathered[wv][0][lane], t = gathered[wv][1][lane];
-    sums[wb + (size_t)lane] = mb >= 32 ? t : t - ((t - w0) << mb);
+  // lane 4 i + part adds rows 8 part .. 8 part + 7 of the wave's i-th (half-wave, step) pair; two DPP steps bring the
+  // four parts together in the quad's last lane, which also holds row 31's share; row 0's comes from the quad's first
+  {
+    const int i = lane >> 2, part = lane & 3;
+    const int hh = i / U, uu = i % U;
+    const u32x4 *eight = reinterpret_cast<const u32x4 *>(&shares[wv][hh][uu][8 * part]);
+    const u32x4 a4 = eight[0], b4 = eight[1];
+    uint32_t t = (a4.x + a4.y + a4.z) + (a4.w + b4.x + b4.y) + (b4.z + b4.w);
+    t += dpp0<DPP_ROW_SHR1>(t) & ((part & 1) ? 0xFFFFFFFFu : 0u);  // parts 1 and 3 take their neighbour's sum
+    const uint32_t pair = dpp0<DPP_ROW_SHR2>(t);                    // part 3 takes parts 0 + 1
+    t += pair;
+    const uint32_t w0 = dpp0<0x113>(a4.x);  // row_shr:3: the first row's share, from the quad's first lane
+    const size_t blk = wb + (size_t)(2 * uu + hh);
+    const uint32_t bb = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * (2 * uu + hh), (int)mb);
+    if (part == 3 && blk < nblocks) sums[blk] = bb >= 32 ? b4.w : t - ((t - w0) << bb);
   }
 }
 

@@ -21,8 +21,14 @@ def main():
     one = lambda pat: sorted(glob.glob(os.path.join(src, pat)))[-1]
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "summarize_profiles.py"), rnd, one("stats/vm/*_kernel_stats.csv"),
                            one("fetch/vm/*counter_collection.csv"), one("write/vm/*counter_collection.csv")], stdout=subprocess.DEVNULL)
+    for name in ("entrypoints", "lanes", "lengths"):
+        if os.path.exists(os.path.join(src, name + ".log")):
+            shutil.copy(os.path.join(src, name + ".log"), os.path.join(out, f"r{rnd}_microbench_{name}.log"))
+    if os.path.isdir(os.path.join(src, "pmc_stream")):
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), os.path.join(out, f"r{rnd}_pmc_stream.json")]
+                              + sorted(glob.glob(os.path.join(src, "pmc_stream", "*"))), stdout=subprocess.DEVNULL)
     for line in open(os.path.join(src, "microbench.log")):
-        for tag in ("stream", "mixed"):
+        for tag in ("stream", "mixed", "query"):
             if line.startswith(tag + " "):
                 json.dump(json.loads(line.split(" ", 1)[1]), open(os.path.join(out, f"r{rnd}_microbench_{tag}.json"), "w"), indent=1)
     rows = list(csv.DictReader(open(one("stream_stats/vm/*_kernel_stats.csv"))))
