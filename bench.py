@@ -309,9 +309,14 @@ def corpus_description(total_blocks):
     simdcomp_hip_partition_by_bytes cuts on."""
     from simdcomp_amd import synth
 
-    widths = synth.ramped_widths(MIXED_SEED, total_blocks, 1, 8, 20)
+    widths = np.empty(total_blocks, dtype=np.uint8)
+    step = 1 << 22  # in pieces: the generator's temporaries are 8-byte words, and eight ranks do this side by side
+    for at in range(0, total_blocks, step):
+        cnt = min(step, total_blocks - at)
+        widths[at:at + cnt] = synth.ramped_widths(MIXED_SEED, cnt, 1, 8, 20, start=at, total=total_blocks)
     prefix = np.zeros(total_blocks + 1, dtype=np.uint64)
-    np.cumsum(widths.astype(np.uint64) * np.uint64(16), out=prefix[1:])
+    np.cumsum(widths, dtype=np.uint64, out=prefix[1:])
+    prefix *= np.uint64(16)
     return widths, prefix
 
 

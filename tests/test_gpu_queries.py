@@ -155,3 +155,51 @@ def test_batched_queries_uniform_for(dev, orc, bit):
     for k in range(nblk):
         want = orc.simdsearchwithlengthFOR(int(base[k]), h[k * 16 * bit:(k + 1) * 16 * bit], bit, int(lengths[k]), int(keys[k]))
         assert (int(pos[k]), int(u32(val[k:k + 1])[0])) == want, (bit, k)
+
+
+@pytest.mark.parametrize("mode", [FOR, PLAIN])
+def test_batched_queries_for_and_plain_with_runs(dev, orc, mode):
+    """Frame-of-reference and plain blocks with per-block widths, batches in which neighbouring queries share a block
+    (runs of every length) and batches that do not: simdselectFOR / simdsearchwithlengthFOR per query on the host
+    as the reference would be called (plain = frame base 0), blocks sorted and unsorted inside."""
+    import torch
+
+    nblk, nq = 700, 9001
+    widths = synth.skewed_widths(91, nblk, 0, 32)
+    x, base = synth.clustered(92, nblk, widths)
+    if mode == PLAIN:
+        x = (x.reshape(nblk, 128) - base[:, None]).astype(np.uint32).reshape(-1)
+        base = np.zeros(nblk, np.uint32)
+    xs = x.reshape(nblk, 128).copy()
+    xs[::2] = np.sort(xs[::2], axis=1)  # every other block sorted: the bisection is defined on any content
+    x = xs.reshape(-1)
+    bits = to_dev(widths)
+    off, total = dev.payload_offsets(bits)
+    arena = torch.zeros(int(total.item()) + 16, dtype=torch.uint8, device="cuda")
+    dev.pack_mixed(mode, to_dev(x), bits, off, arena, initvalues=to_dev(base) if mode == FOR else None)
+    h_arena, h_off = arena.cpu().numpy(), off.cpu().numpy()
+    for order in ("random", "sorted", "hot"):
+        qb = (synth.rand_u32(93, nq) % np.uint32(nblk)).astype(np.uint64)
+        if order == "hot":
+            qb = (qb % np.uint64(11)) * np.uint64(60)
+        if order != "random":
+            qb = np.sort(qb)
+        slots = (synth.rand_u32(94, nq) % np.uint32(128)).astype(np.int32)
+        lengths = (synth.rand_u32(95, nq) % np.uint32(129)).astype(np.int32)
+        pick = xs[qb.astype(np.int64), synth.rand_u32(96, nq) % np.uint32(128)]
+        keys = (pick + (synth.rand_u32(97, nq) % np.uint32(3)) - np.uint32(1)).astype(np.uint32)
+        kw = dict(bits=bits, offsets=off, query_blocks=to_dev(qb))
+        if mode == FOR:
+            kw["initvalues"] = to_dev(base)
+        got = dev.select(mode, arena, to_dev(slots), **kw)
+        assert np.array_equal(u32(got), xs[qb.astype(np.int64), slots]), (mode, order)
+        pos, val = dev.search(mode, arena, to_dev(keys), lengths=to_dev(lengths), **kw)
+        pos, val = pos.cpu().numpy(), u32(val)
+        for q in range(0, nq, 7):
+            k = int(qb[q])
+            b = int(widths[k])
+            comp = np.concatenate([h_arena[int(h_off[k]):int(h_off[k]) + 16 * b], np.zeros(16, np.uint8)])
+            wpos, wval = orc.simdsearchwithlengthFOR(int(base[k]), comp, b, int(lengths[q]), int(keys[q]))
+            if wpos == 128:
+                wval = 0  # the reference reads past the block there; the batched form reports 0
+            assert (int(pos[q]), int(val[q])) == (wpos, wval), (mode, order, q, b)
