@@ -154,3 +154,78 @@ def test_per_block_widths_and_stream(dev, orc, seed):
         assert T == want.size and np.array_equal(to_np(buf)[:T], want)
         out, res = dev.stream_decode(0, buf[:T].clone(), nblk)
         assert res.tolist() == [nblk, T - nblk, 0] and np.array_equal(to_np(out), x)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_query_batches(dev, orc, seed):
+    """Batched search / select with the batch's structure drawn at random: how many queries, how long the runs of
+    queries on one block are, ascending or shuffled block order, d1 or frame of reference, one width or per-block
+    widths (0-bit and raw 32-bit blocks included), lengths 0..128, the offset vector simdsearchd1 leaves behind."""
+    import torch
+
+    rng = np.random.default_rng(8000 + seed)
+    for _ in range(ROUNDS):
+        nblk = int(rng.choice([1, 2, 3, 17, 64, 65, 300]))
+        mode = int(rng.choice([1, 2]))  # d1, frame of reference
+        uniform = bool(rng.integers(0, 2))
+        widths = np.full(nblk, int(rng.integers(0, 33)), np.int64) if uniform else rng.integers(0, 33, nblk)
+        x = synth.rand_u32(int(rng.integers(1, 1 << 30)), nblk * 128).reshape(nblk, 128)
+        for k in range(nblk):
+            if widths[k] < 32:
+                x[k] &= synth.mask(int(widths[k]))
+        seeds = synth.rand_u32(int(rng.integers(1, 1 << 30)), nblk) >> np.uint32(rng.integers(0, 8))
+        if mode == 1:
+            vals = np.empty_like(x)
+            for k in range(nblk):  # gaps -> values, from the block's own seed (a raw block keeps its words)
+                vals[k] = x[k] if widths[k] == 32 else (np.cumsum(x[k].astype(np.uint64)) + np.uint64(seeds[k])).astype(np.uint32)
+        else:
+            vals = (x + seeds[:, None]).astype(np.uint32)
+            raw = widths == 32
+            vals[raw] = x[raw]
+        bits = to_dev(widths.astype(np.uint8))
+        off, total = dev.payload_offsets(bits)
+        arena = torch.zeros(int(total.item()) + 16, dtype=torch.uint8, device="cuda")
+        dev.pack_mixed(mode, to_dev(vals.reshape(-1)), bits, off, arena, initvalues=to_dev(seeds))
+        h_arena, h_off = to_np(arena), to_np(off)
+        nq = int(rng.choice([1, 5, 63, 64, 65, 200, 1000]))
+        runs = rng.integers(1, int(rng.choice([2, 5, 70])) + 1, nq)  # run lengths
+        qb = np.repeat(rng.integers(0, nblk, nq), runs)[:nq]
+        if rng.integers(0, 2):
+            qb = np.sort(qb)
+        qb = qb.astype(np.uint64)
+        lengths = rng.integers(0, 129, nq).astype(np.int32)
+        if mode == 1:
+            lengths[widths[qb.astype(np.int64)] == 32] = np.maximum(lengths[widths[qb.astype(np.int64)] == 32], 1)
+        keys = (vals[qb.astype(np.int64), rng.integers(0, 128, nq)] + rng.integers(0, 3, nq).astype(np.uint32) - np.uint32(1)).astype(np.uint32)
+        slots = rng.integers(0, 128, nq).astype(np.int32)
+        kw = dict(initvalues=to_dev(seeds), query_blocks=to_dev(qb))
+        if uniform:
+            kw["bit"] = int(widths[0])
+        else:
+            kw.update(bits=bits, offsets=off)
+        got = to_np(dev.select(mode, arena, to_dev(slots), **kw))
+        want_last4 = mode == 1 and bool(rng.integers(0, 2))
+        res = dev.search(mode, arena, to_dev(keys), lengths=to_dev(lengths), want_last4=want_last4, **kw)
+        pos, val = to_np(res[0]).view(np.int32), to_np(res[1])
+        for q in range(nq):
+            k, b = int(qb[q]), int(widths[qb[q]])
+            comp = np.concatenate([h_arena[int(h_off[k]):int(h_off[k]) + 16 * b], np.zeros(16, np.uint8)])
+            if mode == 1:
+                assert int(got[q]) == orc.simdselectd1(int(seeds[k]), comp, b, int(slots[q])), (q, k, b)
+                want = orc.simdsearchwithlengthd1(int(seeds[k]), comp, b, int(lengths[q]), int(keys[q]))
+                assert (int(pos[q]), int(val[q])) == tuple(int(v) for v in want), (q, k, b, int(lengths[q]))
+            else:
+                assert int(got[q]) == orc.simdselectFOR(int(seeds[k]), comp, b, int(slots[q])), (q, k, b)
+                wpos, wval = orc.simdsearchwithlengthFOR(int(seeds[k]), comp, b, int(lengths[q]), int(keys[q]))
+                assert (int(pos[q]), int(val[q])) == (wpos, 0 if wpos == 128 else wval), (q, k, b, int(lengths[q]))
+        if want_last4:
+            # the offset vector is defined for searches over the whole block
+            full = np.nonzero(lengths == 128)[0]
+            last4 = to_np(res[2]).reshape(-1, 4)
+            for q in full[:50]:
+                k, b = int(qb[q]), int(widths[qb[q]])
+                comp = np.concatenate([h_arena[int(h_off[k]):int(h_off[k]) + 16 * b], np.zeros(16, np.uint8)])
+                o4 = np.array([0, 0, 0, seeds[k]], np.uint32)
+                wpos, wval, wo4 = orc.simdsearchd1(o4, comp, b, int(keys[q]))
+                if b != 0:  # (a 0-bit block leaves the caller's vector untouched: the batched form reports the seed four times)
+                    assert np.array_equal(last4[q], wo4), (q, k, b)
