@@ -54,9 +54,9 @@ constexpr size_t SUMS_PER_WG = 8 * SUMS_U;
 // (Measured on 2^23 blocks of 7.5 bits per integer, 0.30 ms: a quarter fewer vector instructions -- the closing
 // reduction below instead of a DPP reduction per block -- changed nothing, and workgroups that touch the payload
 // ahead of the computing ones, as the uniform decoders have them, made it 8 % slower: neither the vector ALU nor the
-// latency of the payload loads bounds this kernel by itself.  Per wave it issues some sixty LDS instructions --
-// hand-over, slot writes, row reads, shares -- next to 205 vector and 11 memory instructions, one dependent chain
-// per step, at eight waves per SIMD.)
+// latency of the payload loads bounds this kernel.  What fits the time is the LDS data path, 128 bytes per cycle and
+// CU: per wave 8 slot writes and 16 row reads of 1 KiB each, some 24 crossbar hand-overs and the shares, about 320
+// cycles, times 2048 waves per CU = 0.27 ms.)
 __global__ __launch_bounds__(256) void k_block_sums(const uint8_t *payload, const uint64_t *off, const uint8_t *bits,
                                                     size_t nblocks, uint32_t stream_layout, uint32_t *sums) {
   constexpr int U = SUMS_U;
