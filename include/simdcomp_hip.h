@@ -17,6 +17,9 @@
  *   - sizes are size_t (the reference's int lengths overflow at 2^30 values);
  *   - return value: 0 on success, a positive hipError_t if a HIP call failed,
  *     or one of the negative SIMDCOMP_HIP_E* codes for a rejected argument.
+ *     A call that launches resets the calling thread's HIP error state first
+ *     (hipGetLastError), so that an earlier failure of the application's own is
+ *     not reported as this call's.
  *     The reference has no error channel (bit > 32 silently does nothing,
  *     src/simdbitpacking.c:14046); here bit > 32 is SIMDCOMP_HIP_EBIT.
  *   - a block's "initvalue" is the reference's initvalue argument: the

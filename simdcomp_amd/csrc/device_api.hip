@@ -24,6 +24,11 @@ int hip_result(hipError_t e, const char *where) {
   return sc::api_fail((int)e, msg);
 }
 
+// The launchers report hipGetLastError() behind their launches, and HIP keeps a thread's last error until somebody
+// reads it: an earlier failure of the application's own (a hipHostRegister that was refused, say) would come back as
+// this call's result.  So the error state is read, i.e. reset, right before the launch.
+#define SC_LAUNCH(call, what) ((void)hipGetLastError(), hip_result((call), (what)))
+
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
@@ -60,7 +65,7 @@ int do_pack(int mode, int masked, uint32_t initvalue, const uint32_t *seeds, con
   a.seed0 = initvalue;
   a.carry_blocks = 0;
   a.stream_layout = stream_layout ? 1u : 0u;
-  return hip_result(sc::launch_pack(mode, masked != 0 && mode != SIMDCOMP_HIP_FOR, false, a,
+  return SC_LAUNCH(sc::launch_pack(mode, masked != 0 && mode != SIMDCOMP_HIP_FOR, false, a,
                                     as_stream(stream)),
                     "pack launch");
 }
@@ -82,7 +87,7 @@ int do_unpack(int mode, uint32_t seed0, const uint32_t *seeds, const void *paylo
   a.bit = bit;
   a.seed0 = seed0;
   a.stream_layout = stream_layout ? 1u : 0u;
-  return hip_result(sc::launch_unpack(mode, false, a, as_stream(stream)), "unpack launch");
+  return SC_LAUNCH(sc::launch_unpack(mode, false, a, as_stream(stream)), "unpack launch");
 }
 
 }  // namespace
@@ -165,7 +170,7 @@ int simdcomp_hip_maxbits(const uint32_t *d_in, size_t nblocks, uint8_t *d_bits, 
   a.in = d_in;
   a.bits_out = d_bits;
   a.nblocks = nblocks;
-  return hip_result(sc::launch_reduce(sc::RED_MAXBITS, a, as_stream(stream)), "maxbits launch");
+  return SC_LAUNCH(sc::launch_reduce(sc::RED_MAXBITS, a, as_stream(stream)), "maxbits launch");
 }
 
 int simdcomp_hip_maxbitsd1(uint32_t initvalue, const uint32_t *d_initvalues, const uint32_t *d_in, size_t nblocks,
@@ -180,7 +185,7 @@ int simdcomp_hip_maxbitsd1(uint32_t initvalue, const uint32_t *d_initvalues, con
   a.bits_out = d_bits;
   a.nblocks = nblocks;
   a.seed0 = initvalue;
-  return hip_result(sc::launch_reduce(sc::RED_MAXBITSD1, a, as_stream(stream)), "maxbitsd1 launch");
+  return SC_LAUNCH(sc::launch_reduce(sc::RED_MAXBITSD1, a, as_stream(stream)), "maxbitsd1 launch");
 }
 
 int simdcomp_hip_maxmin(const uint32_t *d_in, size_t nblocks, uint32_t *d_min, uint32_t *d_max, uint8_t *d_bits,
@@ -194,13 +199,13 @@ int simdcomp_hip_maxmin(const uint32_t *d_in, size_t nblocks, uint32_t *d_min, u
   a.max_out = d_max;
   a.bits_out = d_bits;
   a.nblocks = nblocks;
-  return hip_result(sc::launch_reduce(sc::RED_MINMAX, a, as_stream(stream)), "maxmin launch");
+  return SC_LAUNCH(sc::launch_reduce(sc::RED_MINMAX, a, as_stream(stream)), "maxmin launch");
 }
 
 int simdcomp_hip_reduce_length(const uint32_t *d_in, size_t length, uint32_t initvalue, uint32_t *d_result4,
                                void *stream) {
   if (!d_result4 || (!d_in && length)) return fail(SIMDCOMP_HIP_ENULL, "NULL pointer");
-  return hip_result(sc::launch_reduce_array(d_in, length, initvalue, d_result4, as_stream(stream)), "reduce launch");
+  return SC_LAUNCH(sc::launch_reduce_array(d_in, length, initvalue, d_result4, as_stream(stream)), "reduce launch");
 }
 
 size_t simdcomp_hip_payload_offsets_workspace(size_t nblocks) { return sc::scan_workspace_bytes(nblocks); }
@@ -208,7 +213,7 @@ size_t simdcomp_hip_payload_offsets_workspace(size_t nblocks) { return sc::scan_
 int simdcomp_hip_payload_offsets(const uint8_t *d_bits, size_t nblocks, uint64_t *d_payload_offsets,
                                  uint64_t *d_total_bytes, void *d_workspace, void *stream) {
   if (nblocks && (!d_bits || !d_payload_offsets || !d_workspace)) return fail(SIMDCOMP_HIP_ENULL, "NULL pointer");
-  return hip_result(sc::launch_payload_offsets(d_bits, nblocks, d_payload_offsets, d_total_bytes, d_workspace,
+  return SC_LAUNCH(sc::launch_payload_offsets(d_bits, nblocks, d_payload_offsets, d_total_bytes, d_workspace,
                                                as_stream(stream)),
                     "payload offsets launch");
 }
@@ -258,7 +263,7 @@ int simdcomp_hip_payload_offsets_noalloc(const uint8_t *d_bits, size_t nblocks, 
   void *ws = nullptr;
   if (int rc = scratch_on_current_device(&ws)) return rc;
   // nothing in the scratch has to start at zero: the first kernel writes every tile sum the later ones read
-  return hip_result(sc::launch_payload_offsets(d_bits, nblocks, d_payload_offsets, d_total_bytes, ws, as_stream(stream)),
+  return SC_LAUNCH(sc::launch_payload_offsets(d_bits, nblocks, d_payload_offsets, d_total_bytes, ws, as_stream(stream)),
                     "payload offsets launch");
 }
 
@@ -278,7 +283,7 @@ int simdcomp_hip_pack_length(const uint32_t *d_in, size_t length, void *d_out, u
     a.nblocks = 1;
     a.length = rest;
     a.bit = bit;
-    return hip_result(sc::launch_pack(sc::MODE_PLAIN, false, true, a, as_stream(stream)), "pack tail launch");
+    return SC_LAUNCH(sc::launch_pack(sc::MODE_PLAIN, false, true, a, as_stream(stream)), "pack tail launch");
   }
   return SIMDCOMP_HIP_OK;
 }
@@ -301,7 +306,7 @@ static int unpack_length_common(int mode, uint32_t initvalue, const void *d_in, 
     a.length = rest;
     a.bit = bit;
     a.seed0 = initvalue;
-    return hip_result(sc::launch_unpack(mode, true, a, as_stream(stream)), "unpack tail launch");
+    return SC_LAUNCH(sc::launch_unpack(mode, true, a, as_stream(stream)), "unpack tail launch");
   }
   return SIMDCOMP_HIP_OK;
 }
@@ -327,7 +332,7 @@ int simdcomp_hip_packFOR_length(uint32_t initvalue, const uint32_t *d_in, size_t
   a.seed0 = initvalue;
   a.carry_blocks = 1;
   a.carry_first = carry_in != 0;
-  return hip_result(sc::launch_pack(sc::MODE_FOR, false, true, a, as_stream(stream)), "packFOR_length launch");
+  return SC_LAUNCH(sc::launch_pack(sc::MODE_FOR, false, true, a, as_stream(stream)), "packFOR_length launch");
 }
 
 int simdcomp_hip_unpackFOR_length(uint32_t initvalue, const void *d_in, size_t length, uint32_t *d_out,
@@ -345,7 +350,7 @@ int simdcomp_hip_chain_offsets(uint32_t initvalue, const void *d_payload, const 
     return fail(SIMDCOMP_HIP_ENULL, "NULL pointer");
   if ((!stream_layout && !aligned16(d_payload)) || !aligned16(d_workspace))
     return fail(SIMDCOMP_HIP_EALIGN, "pointer not 16-byte aligned");
-  return hip_result(sc::launch_chain_offsets(initvalue, d_payload, d_payload_offsets, d_bits, nblocks, stream_layout != 0,
+  return SC_LAUNCH(sc::launch_chain_offsets(initvalue, d_payload, d_payload_offsets, d_bits, nblocks, stream_layout != 0,
                                              d_initvalues_out, d_workspace, as_stream(stream)),
                     "chain offsets launch");
 }
@@ -355,7 +360,7 @@ int simdcomp_hip_stream_build(const void *d_payload, const uint64_t *d_payload_o
   if (nblocks == 0) return SIMDCOMP_HIP_OK;
   if (!d_payload || !d_payload_offsets || !d_bits || !d_stream) return fail(SIMDCOMP_HIP_ENULL, "NULL pointer");
   if (!aligned16(d_payload)) return fail(SIMDCOMP_HIP_EALIGN, "payload arena not 16-byte aligned");
-  return hip_result(sc::launch_stream_build(d_payload, d_payload_offsets, d_bits, nblocks,
+  return SC_LAUNCH(sc::launch_stream_build(d_payload, d_payload_offsets, d_bits, nblocks,
                                             static_cast<uint8_t *>(d_stream), as_stream(stream)),
                     "stream build launch");
 }
@@ -365,7 +370,7 @@ int simdcomp_hip_stream_unbuild(const void *d_stream, const uint64_t *d_payload_
   if (nblocks == 0) return SIMDCOMP_HIP_OK;
   if (!d_payload || !d_payload_offsets || !d_bits || !d_stream) return fail(SIMDCOMP_HIP_ENULL, "NULL pointer");
   if (!aligned16(d_payload)) return fail(SIMDCOMP_HIP_EALIGN, "payload arena not 16-byte aligned");
-  return hip_result(sc::launch_stream_unbuild(static_cast<const uint8_t *>(d_stream), d_payload_offsets, d_bits, nblocks,
+  return SC_LAUNCH(sc::launch_stream_unbuild(static_cast<const uint8_t *>(d_stream), d_payload_offsets, d_bits, nblocks,
                                               d_payload, as_stream(stream)),
                     "stream unbuild launch");
 }
@@ -378,7 +383,7 @@ int simdcomp_hip_stream_index(const void *d_stream, size_t stream_bytes, size_t 
   if (stream_bytes && (!d_stream || !d_workspace)) return fail(SIMDCOMP_HIP_ENULL, "NULL pointer");
   if (stream_bytes && max_blocks && (!d_bits || !d_payload_offsets)) return fail(SIMDCOMP_HIP_ENULL, "NULL output array");
   if (!aligned16(d_workspace)) return fail(SIMDCOMP_HIP_EALIGN, "workspace not 16-byte aligned");
-  return hip_result(sc::launch_stream_index(static_cast<const uint8_t *>(d_stream), stream_bytes, max_blocks, d_bits,
+  return SC_LAUNCH(sc::launch_stream_index(static_cast<const uint8_t *>(d_stream), stream_bytes, max_blocks, d_bits,
                                             d_payload_offsets, d_result, d_workspace, /*clear_tail=*/false, as_stream(stream)),
                     "stream index launch");
 }
@@ -409,7 +414,7 @@ int simdcomp_hip_stream_compress(int mode, uint32_t initvalue, const uint32_t *d
   if (rc) return rc;
   if ((rc = simdcomp_hip_payload_offsets(bits, nblocks, off, total, scan_ws, stream))) return rc;
   if ((rc = simdcomp_hip_pack_stream(mode, 0, initvalue, nullptr, d_in, d_stream, off, bits, nblocks, nullptr, stream))) return rc;
-  return hip_result(sc::launch_stream_bytes(total, nblocks, d_stream_bytes, as_stream(stream)), "stream bytes launch");
+  return SC_LAUNCH(sc::launch_stream_bytes(total, nblocks, d_stream_bytes, as_stream(stream)), "stream bytes launch");
 }
 
 size_t simdcomp_hip_stream_decode_workspace(size_t stream_bytes, size_t nblocks) {
@@ -432,7 +437,7 @@ int simdcomp_hip_stream_decode(int mode, uint32_t initvalue, const void *d_strea
   uint8_t *chain_ws = index_ws + up256(sc::stream_index_workspace_bytes(stream_bytes));
   // a stream with fewer records than nblocks leaves the rest as zero-width blocks at offset 0 (d_result[0] tells): the
   // index clears exactly those entries (all of them before it writes what it finds, when the stream is bad)
-  int rc = hip_result(sc::launch_stream_index(static_cast<const uint8_t *>(d_stream), stream_bytes, nblocks, bits, off, d_result,
+  int rc = SC_LAUNCH(sc::launch_stream_index(static_cast<const uint8_t *>(d_stream), stream_bytes, nblocks, bits, off, d_result,
                                               index_ws, /*clear_tail=*/true, as_stream(stream)),
                       "stream index launch");
   if (rc) return rc;
@@ -461,7 +466,7 @@ int do_query(int mode, int what, uint32_t initvalue, const uint32_t *d_initvalue
   a.bit = bit;
   a.seed0 = initvalue;
   a.stream_layout = stream_layout ? 1u : 0u;
-  return hip_result(sc::launch_query(mode, what, a, as_stream(stream)), "query launch");
+  return SC_LAUNCH(sc::launch_query(mode, what, a, as_stream(stream)), "query launch");
 }
 }  // namespace
 
@@ -524,7 +529,7 @@ int simdcomp_hip_pack_lanes(int lanes, const uint32_t *d_in, void *d_out, size_t
   a.nblocks = nblocks * a.lane_groups;
   a.length = a.nblocks * 128;
   a.bit = bit;
-  return hip_result(sc::launch_pack(sc::MODE_PLAIN, masked != 0, false, a, as_stream(stream)), "pack launch");
+  return SC_LAUNCH(sc::launch_pack(sc::MODE_PLAIN, masked != 0, false, a, as_stream(stream)), "pack launch");
 }
 
 int simdcomp_hip_unpack_lanes(int lanes, const void *d_in, uint32_t *d_out, size_t nblocks, uint32_t bit, void *stream) {
@@ -537,7 +542,7 @@ int simdcomp_hip_unpack_lanes(int lanes, const void *d_in, uint32_t *d_out, size
   a.nblocks = nblocks * a.lane_groups;
   a.length = a.nblocks * 128;
   a.bit = bit;
-  return hip_result(sc::launch_unpack(sc::MODE_PLAIN, false, a, as_stream(stream)), "unpack launch");
+  return SC_LAUNCH(sc::launch_unpack(sc::MODE_PLAIN, false, a, as_stream(stream)), "unpack launch");
 }
 
 int simdcomp_hip_maxbits_lanes(int lanes, const uint32_t *d_in, size_t nblocks, uint8_t *d_bits, void *stream) {
@@ -550,14 +555,14 @@ int simdcomp_hip_maxbits_lanes(int lanes, const uint32_t *d_in, size_t nblocks, 
   a.in = d_in;
   a.bits_out = d_bits;
   a.nblocks = nblocks;
-  return hip_result(sc::launch_reduce(sc::RED_MAXBITS, a, as_stream(stream)), "maxbits launch");
+  return SC_LAUNCH(sc::launch_reduce(sc::RED_MAXBITS, a, as_stream(stream)), "maxbits launch");
 }
 
 int simdcomp_hip_checksum(const uint32_t *d_data, const uint32_t *d_other, size_t nwords, uint64_t index0,
                           uint64_t *d_acc, void *stream) {
   if (nwords == 0) return SIMDCOMP_HIP_OK;
   if (!d_data || !d_acc) return fail(SIMDCOMP_HIP_ENULL, "NULL pointer");
-  return hip_result(sc::launch_checksum(d_data, d_other, nwords, index0, d_acc, as_stream(stream)), "checksum launch");
+  return SC_LAUNCH(sc::launch_checksum(d_data, d_other, nwords, index0, d_acc, as_stream(stream)), "checksum launch");
 }
 
 }  // extern "C"

@@ -239,6 +239,9 @@ struct Call {
   Call() {
     Pool &p = pool();
     if (p.bad_where) die(p.bad_where, p.bad_what);
+    // HIP keeps a thread's last error until it is read: a failure of the application's own before this call must
+    // not surface as a failed launch of ours
+    (void)hipGetLastError();
     ck(hipGetDevice(&prev), "hipGetDevice");
     if (p.devices.empty()) {
       dev = prev;

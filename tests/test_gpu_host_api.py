@@ -342,3 +342,34 @@ print("ok")
         env = dict(os.environ, SIMDCOMP_HIP_POLL=poll)
         out = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=300, env=env)
         assert out.returncode == 0 and out.stdout.strip().endswith("ok"), (poll, out.stdout[-500:], out.stderr[-2000:])
+
+
+def test_an_earlier_hip_error_of_the_caller_is_not_reported_as_ours(lib, orc):
+    """HIP keeps a thread's last error until somebody reads it.  A failed HIP call of the application (here: an
+    unregister of memory that was never registered) must not come back as the result of the next library call,
+    batched or through the reference signatures."""
+    import torch
+
+    from simdcomp_amd import codec
+
+    rt = torch.cuda.cudart()
+    x = synth.random_bits(5, 128 * 40, 9)
+    d_x = torch.from_numpy(x.view(np.int32)).cuda()
+    scratch = np.zeros(4096, np.uint8)
+    for _ in range(2):
+        try:
+            rc = rt.cudaHostUnregister(scratch.ctypes.data)  # fails: sets the thread's last error
+        except RuntimeError:
+            rc = 1
+        assert rc != 0 and int(rc) != 0
+        pay = codec.pack(d_x, 9, masked=True)  # raises if the call reports an error
+        assert np.array_equal(pay.cpu().numpy(), orc.batch_pack("plain", x, 9, masked=True))
+        try:
+            rt.cudaHostUnregister(scratch.ctypes.data)
+        except RuntimeError:
+            pass
+        out = np.zeros(128, np.uint32)
+        buf = np.zeros(16 * 9, np.uint8)
+        lib.simdpack(p(x[:128].copy()), p(buf), 9)
+        lib.simdunpack(p(buf), p(out), 9)
+        assert np.array_equal(out, x[:128])
