@@ -99,7 +99,9 @@ int simdcomp_hip_unpackFOR(const uint32_t *d_initvalues, const void *d_in, uint3
 
 /* ---- per-block widths: the caller convention of example.c:56-75,135-150 ----
  * d_bits[k] is block k's width, d_payload_offsets[k] the byte offset of its
- * payload inside d_payload (see simdcomp_hip_payload_offsets).  mode is one of
+ * payload inside d_payload (see simdcomp_hip_payload_offsets; d_payload is ONE
+ * buffer: the decoder may also read bytes that lie between two payloads, ahead
+ * of decoding them).  mode is one of
  * SIMDCOMP_HIP_PLAIN / _D1 / _FOR; masked and the initvalue arguments are as in
  * the uniform calls (FOR ignores masked). */
 int simdcomp_hip_pack_mixed(int mode, int masked, uint32_t initvalue, const uint32_t *d_initvalues,

@@ -454,6 +454,17 @@ __device__ __forceinline__ void touch_bytes(const void *base, size_t byte0, size
 #ifndef SC_NT_MIXED_UNPACK
 #define SC_NT_MIXED_UNPACK 0
 #endif
+// per-block widths: the prefetch workgroups also touch a group's payload when its blocks average at most this many
+// bits (0: never), at DIST4 quarters of the metadata's distance.  Measured with 2^30 integers: groups of 3 / 4 / 5 / 6
+// bits decode 17 / 15 / 11 / 4 % faster, 7 bits and more gain nothing and a corpus of random widths averaging 7.2
+// bits loses 4 % (so the limit is 6); the payload must be fetched 30-40 MiB of output ahead -- at 5 MiB the same
+// prefetch costs 3-6 %, at 10 MiB it changes nothing, at 20 MiB it gains two thirds of what it gains at 30.
+#ifndef SC_PF_MIXED_PAYLOAD_MAXB
+#define SC_PF_MIXED_PAYLOAD_MAXB 6
+#endif
+#ifndef SC_PF_MIXED_PAYLOAD_DIST4
+#define SC_PF_MIXED_PAYLOAD_DIST4 2
+#endif
 template <int B, int MODE, int U, int BS, int PF = 0, int LS = 0>
 __global__ __launch_bounds__(BS) void k_unpack_fast(UnpackArgs a, uint32_t nwg = 0, uint32_t dist = 0) {
   static_assert(LS == 0 || (B >= 0 && MODE == MODE_PLAIN), "wide layouts: uniform width, plain coding");
@@ -483,11 +494,43 @@ __global__ __launch_bounds__(BS) void k_unpack_fast(UnpackArgs a, uint32_t nwg =
           if constexpr (MODE != MODE_PLAIN)
             touch_bytes<BS, GB * 4>(a.seeds ? static_cast<const void *>(a.seeds) : a.payload, t * GB * 4, nblk * 4 - 1, acc);
         } else {
-          // per-block widths: the metadata only (widths, payload offsets, seeds), so that the decode waves' first
-          // round of loads hits the cache; the payload's place is not known here
+          // per-block widths: the metadata (widths, payload offsets, seeds), so that the decode waves' first
+          // round of loads hits the cache; where the payload lies is in that metadata (below)
           touch_bytes<BS, GB>(a.bits, t * GB, nblk - 1, acc);
           touch_bytes<BS, GB * 8>(a.off, t * GB * 8, nblk * 8 - 1, acc);
           if constexpr (MODE != MODE_PLAIN) touch_bytes<BS, GB * 4>(a.seeds, t * GB * 4, nblk * 4 - 1, acc);
+        }
+      }
+      if constexpr (B < 0 && SC_PF_MIXED_PAYLOAD_MAXB > 0) {
+        // ... and the payload of the group(s) a fraction of that distance ahead, whose metadata an earlier prefetcher
+        // has brought in: the bytes from the first block's payload to the end of the last block's, if that is a span
+        // a group of narrow blocks laid end to end could fill (payloads in any other order are left alone)
+        const size_t hp = (size_t)dist * SC_PF_MIXED_PAYLOAD_DIST4 / 4;
+        const size_t p0 = (size_t)group + (group + 1 < hp ? group + 1 : hp);
+        const size_t p1 = (size_t)group + 1 + (group + 2 < hp ? group + 2 : hp);
+        for (size_t p = p0; p < p1 && hp > 0; ++p) {
+          const size_t fb = p * GB;
+          if (fb >= nblk) break;
+          const size_t lb = (fb + GB < nblk ? fb + GB : nblk) - 1;
+          const uint32_t wl = a.bits[lb];
+          uint64_t lo = a.off[fb], hi = a.off[lb] + 16 * (uint64_t)(wl > 32 ? 32 : wl);
+          if (a.stream_layout) {
+            lo += a.block_base + fb + 1;
+            hi += a.block_base + lb + 1;
+          }
+          const uint64_t span = hi - lo;  // (wraps to a huge value when the last block lies in front of the first)
+          if (span - 1 < (uint64_t)(lb - fb + 1) * (16 * SC_PF_MIXED_PAYLOAD_MAXB + 1)) {
+            // a fixed number of loads, all in flight together; those past the end re-read the last vector
+            constexpr int TRIPS = (int)((GB * (16 * SC_PF_MIXED_PAYLOAD_MAXB + 1) / 16 + BS) / BS);
+            const uintptr_t v0 = (reinterpret_cast<uintptr_t>(a.payload) + lo) >> 4;
+            const uintptr_t vlast = (reinterpret_cast<uintptr_t>(a.payload) + hi - 1) >> 4;
+#pragma unroll
+            for (int trip = 0; trip < TRIPS; ++trip) {
+              uintptr_t v = v0 + (uintptr_t)trip * BS + threadIdx.x;
+              v = v < vlast ? v : vlast;
+              acc |= load_global_at(v << 4);
+            }
+          }
         }
       }
       asm volatile("" ::"v"(acc));  // keeps the loads; the only wait of this workgroup
@@ -1225,10 +1268,11 @@ constexpr int unpack_steps(int b) { return (b >= SC_UM_LO && b <= SC_UM_HI) ? SC
 // payload is a large enough share of the traffic that the extra reads cost
 // more than the latency they hide.  b = 1 is sharper than the others: on most boxes its rate
 // peaks at 10 MiB (72 / 79 / 81 / 82 / 81 / 79 / 77 / 76 % at 4 / 6 / 8 / 10 / 12 / 14 / 16 / 20 MiB), on the
-// others it runs at 85 % at either distance.  The per-block-width decoder cannot prefetch its payload (the
-// prefetcher would have to chase offsets itself, and its scattered touches cost more than they save), but it gains
-// 4-7 % from one prefetcher per 8 decode workgroups that touches the metadata only (widths, offsets, seeds, 10 MiB
-// of output ahead): the decode waves' first round of loads then hits the cache and they wait for HBM once, not twice.
+// others it runs at 85 % at either distance.  The per-block-width decoder gains 4-7 % from one prefetcher per 8
+// decode workgroups that touches the metadata (widths, offsets, seeds, 60 MiB of output ahead): the decode waves'
+// first round of loads then hits the cache and they wait for HBM once, not twice.  Half that distance ahead the
+// metadata is in the cache for the prefetcher too, which reads where a group's payload begins and ends and touches
+// it when the group is narrow (SC_PF_MIXED_PAYLOAD_MAXB above).
 #ifndef SC_PF_GROUP
 #define SC_PF_GROUP 16
 #endif
@@ -1252,7 +1296,7 @@ constexpr int unpack_prefetch_group(int b) { return b < 0 ? SC_PF_MIXED : ((b >=
 #define SC_PF_DIST1_MIB 10
 #endif
 #ifndef SC_PF_DISTM_MIB
-#define SC_PF_DISTM_MIB 10
+#define SC_PF_DISTM_MIB 60
 #endif
 constexpr size_t prefetch_distance_bytes(int b) { return (size_t)(b < 0 ? SC_PF_DISTM_MIB : (b == 1 ? SC_PF_DIST1_MIB : (b >= SC_PF_HI_MINB ? SC_PF_DIST_HI_MIB : SC_PF_DIST_MIB))) << 20; }
 

@@ -198,6 +198,42 @@ def test_mixed_widths(dev, orc):
         assert np.array_equal(to_np(dec), orc.batch_unpack(name, want, nblk, seeds=base, bits=wb, off=pos[:-1].copy()))
 
 
+@pytest.mark.parametrize("layout", ["arena", "stream", "reversed", "padded"])
+def test_long_narrow_mixed_widths(dev, orc, layout):
+    """Groups of narrow blocks have their payload touched ahead of the decoding workgroups, from where the first
+    block's payload starts to where the last one's ends: long enough to leave the start-up ramp of that distance,
+    with the payloads end to end (aligned arena, byte stream), in descending order, and with gaps between them."""
+    import torch
+
+    nblk = 256 * 700 + 45
+    wb = np.minimum(synth.rand_u32(80, nblk) % 8, synth.rand_u32(81, nblk) % 13).astype(np.uint8)  # 0..7, mostly small
+    wb[5000:5600] = 32  # a stretch of raw blocks: its groups are left alone
+    sizes = wb.astype(np.uint64) * 16
+    pos = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+    total = int(pos[-1])
+    gaps = synth.rand_u32(82, nblk * 128) & np.repeat(((np.uint64(1) << wb.astype(np.uint64)) - 1).astype(np.uint32), 128)
+    ids = np.cumsum(gaps, dtype=np.uint32)
+    seeds = synth.block_offsets(ids, 0)
+    if layout == "stream":
+        strm = torch.empty(total + nblk, dtype=torch.uint8, device="cuda")
+        dev.pack_stream(1, to_dev(ids), to_dev(wb), to_dev(pos[:-1].copy()), strm, initvalue=0)
+        dec = dev.unpack_stream(1, strm, to_dev(wb), to_dev(pos[:-1].copy()), nblk, initvalues=to_dev(seeds))
+        assert np.array_equal(to_np(dec), ids)
+        return
+    if layout == "arena":
+        off, nbytes = pos[:-1].copy(), total
+    elif layout == "reversed":
+        off, nbytes = (np.uint64(total) - pos[1:]).astype(np.uint64), total
+    else:
+        off, nbytes = (pos[:-1] + np.arange(nblk, dtype=np.uint64) * 16).astype(np.uint64), total + 16 * nblk
+    want = orc.batch_pack("d1", ids, seeds=seeds, bits=wb, off=off.copy(), out_bytes=nbytes)
+    payload = torch.zeros(nbytes + 16, dtype=torch.uint8, device="cuda")
+    dev.pack_mixed(1, to_dev(ids), to_dev(wb), to_dev(off), payload, initvalues=to_dev(seeds))
+    assert np.array_equal(to_np(payload)[:nbytes], want)
+    dec = dev.unpack_mixed(1, payload, to_dev(wb), to_dev(off), nblk, initvalues=to_dev(seeds))
+    assert np.array_equal(to_np(dec), ids)
+
+
 @pytest.mark.parametrize("bit", BITS)
 def test_lengths(dev, orc, bit):
     full = {"inrange": synth.random_bits(60, 20011, bit), "wild": synth.rand_u32(61, 20011)}
