@@ -229,6 +229,25 @@ def test_public_headers_compile_as_plain_c_and_cxx(tmp_path):
         assert r.returncode == 0, r.stderr
 
 
+def test_example_program_compiles_and_links(tmp_path):
+    """examples/device_postings.c is the plain-C caller of the device API: it has to compile without warnings and link
+    against the in-tree library with nothing but HIP's runtime header and library (no GPU needed for that)."""
+    import shutil
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists("/opt/rocm/include/hip/hip_runtime_api.h"):
+        pytest.skip("no HIP runtime header")
+    cc = shutil.which("gcc") or shutil.which("cc")
+    for std in ("c99", "c11", "gnu89"):
+        r = subprocess.run([cc, "-std=" + std, "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                            "-I", os.path.join(root, "include"), os.path.join(root, "examples", "device_postings.c"),
+                            "-L", os.path.join(root, "simdcomp_amd"), "-lsimdcomp_hip", "-L/opt/rocm/lib", "-lamdhip64",
+                            "-Wl,-rpath," + os.path.join(root, "simdcomp_amd"), "-Wl,-rpath,/opt/rocm/lib",
+                            "-o", str(tmp_path / ("example_" + std))], capture_output=True, text=True)
+        assert r.returncode == 0, (std, r.stderr[-2000:])
+
+
 def test_workspace_sizes_are_consistent():
     """The workspace-size functions are plain host arithmetic: multiples of 256, never shrinking with the input, large
     enough for what the kernels keep there (per 16 KiB chunk of stream: a table of 513 words and 1.5 logs of 1 KiB),

@@ -86,3 +86,15 @@ def test_binaries_linked_to_the_reference_library_run_on_this_one(libdir):
     env = dict(os.environ, LD_LIBRARY_PATH=libdir + ":/opt/rocm/lib", LD_TRACE_LOADED_OBJECTS="1")
     trace = subprocess.run([os.path.join(REF_BIN, "example_reflinked")], capture_output=True, text=True, env=env).stdout
     assert f"libsimdcomp.so => {libdir}/libsimdcomp.so" in trace and "libamdhip64" in trace, trace
+
+
+@pytest.mark.timeout(200)
+@pytest.mark.parametrize("nblocks", ["8192", "100003"])
+def test_device_api_example_program(libdir, nblocks):
+    """examples/device_postings.c (plain C against include/simdcomp_hip.h): compress, decode and search a posting
+    list with one call per step; the program checks its results against the input itself."""
+    path = os.path.join(HERE, "..", "examples", "build", "device_postings")
+    assert os.path.exists(path), "examples/build/device_postings is not built (make -C examples)"
+    env = dict(os.environ, LD_LIBRARY_PATH=libdir + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    p = subprocess.run([path, nblocks], capture_output=True, text=True, timeout=180, env=env)
+    assert p.returncode == 0 and p.stdout.strip().endswith("ok"), (p.stdout + p.stderr)[-2000:]
