@@ -454,6 +454,12 @@ __device__ __forceinline__ void touch_bytes(const void *base, size_t byte0, size
 #ifndef SC_NT_MIXED_UNPACK
 #define SC_NT_MIXED_UNPACK 0
 #endif
+// per-block widths: the wave's metadata through the scalar unit (2-5 % faster from 9 bits on and on the byte stream,
+// neutral for 5..8 bits; workgroup shapes re-swept with it: 256 x 2 and 128 x 2 decode blocks of 12..24 bits 3-7 %
+// faster but narrow ones 15-25 % slower, 512 x 4 gains 1 % below 10 bits and loses 4 % at 24: 256 x 4 stays)
+#ifndef SC_MIXED_SCALAR_META
+#define SC_MIXED_SCALAR_META 1
+#endif
 // per-block widths: the prefetch workgroups also touch a group's payload when its blocks average at most this many
 // bits (0: never), at DIST4 quarters of the metadata's distance.  Measured with 2^30 integers: groups of 3 / 4 / 5 / 6
 // bits decode 17 / 15 / 11 / 4 % faster, 7 bits and more gain nothing and a corpus of random widths averaging 7.2
@@ -559,6 +565,35 @@ __global__ __launch_bounds__(BS) void k_unpack_fast(UnpackArgs a, uint32_t nwg =
       // depends on them: two memory latencies, not three
       uint64_t o[U];
       constexpr int NB = 2 * U;
+#if SC_MIXED_SCALAR_META
+      // ... through the scalar unit: the three addresses are the same for the whole wave, the values arrive in scalar
+      // registers, and the wave issues three vector memory instructions fewer
+      typedef const __attribute__((address_space(4))) uint32_t *k32;
+      typedef const __attribute__((address_space(4))) uint64_t *k64;
+      const size_t wbase = tile * per_iter + (size_t)__builtin_amdgcn_readfirstlane(wv) * NB;
+      const k64 offp = (k64)(uintptr_t)(a.off + wbase);
+      const uintptr_t wat = (uintptr_t)(a.bits + wbase);  // 2 * U width bytes at any alignment: the dwords around them
+      const k32 wp = (k32)(wat & ~(uintptr_t)3);
+      const uint32_t sh = (uint32_t)(wat & 3) * 8;
+      static_assert(NB == 8 || NB == 4 || NB == 2, "widths of a wave's blocks: at most 8 bytes");
+      const uint32_t w0 = wp[0], w1 = NB > 4 || sh ? wp[NB > 4 || sh ? 1 : 0] : 0;
+      const uint32_t w2 = NB > 4 ? wp[sh ? 2 : 0] : 0;
+      const uint64_t wlo = ((uint64_t)w1 << 32) | w0;
+      const uint64_t widths = sh ? (wlo >> sh) | ((uint64_t)w2 << (64 - sh)) : wlo;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t b0 = (uint32_t)(widths >> (16 * u)) & 0xFF, b1 = (uint32_t)(widths >> (16 * u + 8)) & 0xFF;
+        const uint32_t bb = h ? b1 : b0;
+        b[u] = bb > 32 ? 32 : bb;  // a width byte above 32 is treated as 32 (nothing is indexed with it)
+        const uint64_t o0 = offp[2 * u], o1 = offp[2 * u + 1];
+        o[u] = h ? o1 : o0;
+        if constexpr (MODE != MODE_PLAIN) {
+          const k32 sp = (k32)(uintptr_t)(a.seeds + wbase);
+          const uint32_t s0 = sp[2 * u], s1 = sp[2 * u + 1];
+          seed[u] = h ? s1 : s0;
+        }
+      }
+#else
       const size_t mine = tile * per_iter + (size_t)wv * NB + (size_t)(lane % NB);
       const uint32_t mb_raw = a.bits[mine];
       const uint64_t mo = a.off[mine];
@@ -568,6 +603,7 @@ __global__ __launch_bounds__(BS) void k_unpack_fast(UnpackArgs a, uint32_t nwg =
       hand_out<U>(mb, h, b);
       hand_out<U>(mo, h, o);
       if constexpr (MODE != MODE_PLAIN) hand_out<U>(ms, h, seed);
+#endif
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const size_t blk = first + 2 * (size_t)u;
@@ -1257,10 +1293,13 @@ constexpr int REDUCE_U = SC_REDUCE_U;
 #define SC_UM_BS 128
 #define SC_UM_U 1
 #endif
-constexpr int unpack_threads(int b) { return (b >= SC_UM_LO && b <= SC_UM_HI) ? SC_UM_BS : b >= SC_UW_MINB ? SC_UW_BS : ((b < 0 || b >= 20) ? 256 : ((b >= 1 && b <= SC_UN_MAXB) ? SC_UN_BS : 128)); }
 #ifndef SC_MIXED_UNPACK_STEPS
 #define SC_MIXED_UNPACK_STEPS 4
 #endif
+#ifndef SC_MIXED_UNPACK_BS
+#define SC_MIXED_UNPACK_BS 256
+#endif
+constexpr int unpack_threads(int b) { return (b >= SC_UM_LO && b <= SC_UM_HI) ? SC_UM_BS : b >= SC_UW_MINB ? SC_UW_BS : (b < 0 ? SC_MIXED_UNPACK_BS : b >= 20 ? 256 : ((b >= 1 && b <= SC_UN_MAXB) ? SC_UN_BS : 128)); }
 constexpr int unpack_steps(int b) { return (b >= SC_UM_LO && b <= SC_UM_HI) ? SC_UM_U : b >= SC_UW_MINB ? SC_UW_U : (b < 0 ? SC_MIXED_UNPACK_STEPS : ((b >= 1 && b <= SC_UN_MAXB) ? SC_UN_U : (b <= 14 ? 2 : 1))); }
 // Widths 1..7 gain 3-17 points of HBM peak from dedicated prefetch workgroups
 // (one per 16 decode workgroups, 20 MiB of output ahead: the plateau of a

@@ -198,6 +198,33 @@ def test_mixed_widths(dev, orc):
         assert np.array_equal(to_np(dec), orc.batch_unpack(name, want, nblk, seeds=base, bits=wb, off=pos[:-1].copy()))
 
 
+@pytest.mark.parametrize("shift", [1, 2, 3, 5])
+def test_mixed_widths_metadata_at_any_alignment(dev, orc, shift):
+    """The decoder fetches a wave's widths, offsets and seeds as aligned words around them: width arrays that start
+    at any byte, offsets and seeds at their natural alignment only."""
+    import torch
+
+    nblk = 3000
+    wb = (synth.rand_u32(90 + shift, nblk) % 33).astype(np.uint8)
+    pos = np.concatenate([[0], np.cumsum(wb.astype(np.uint64) * 16)]).astype(np.uint64)
+    wild = synth.rand_u32(91, nblk * 128)
+    base = synth.rand_u32(92, nblk)
+    bits_buf = torch.full((nblk + 16,), 77, dtype=torch.uint8, device="cuda")
+    bits_buf[shift:shift + nblk] = to_dev(wb)
+    off_buf = torch.zeros(nblk + 1, dtype=torch.int64, device="cuda")
+    off_buf[1:] = to_dev(pos[:-1].copy())
+    seeds_buf = torch.zeros(nblk + 1, dtype=torch.int32, device="cuda")
+    seeds_buf[1:] = to_dev(base)
+    for mode, name in ((0, "plain"), (1, "d1"), (2, "for")):
+        want = orc.batch_pack(name, wild, seeds=base, bits=wb, off=pos[:-1].copy(), out_bytes=int(pos[-1]))
+        dec = dev.unpack_mixed(mode, to_dev(want), bits_buf[shift:shift + nblk], off_buf[1:], nblk, initvalues=seeds_buf[1:])
+        assert np.array_equal(to_np(dec), orc.batch_unpack(name, want, nblk, seeds=base, bits=wb, off=pos[:-1].copy()))
+        payload = torch.zeros(int(pos[-1]) + 16, dtype=torch.uint8, device="cuda")
+        dev.pack_mixed(mode, to_dev(wild), bits_buf[shift:shift + nblk], off_buf[1:], payload, initvalues=seeds_buf[1:],
+                       masked=False)
+        assert np.array_equal(to_np(payload)[: int(pos[-1])], want)
+
+
 @pytest.mark.parametrize("layout", ["arena", "stream", "reversed", "padded"])
 def test_long_narrow_mixed_widths(dev, orc, layout):
     """Groups of narrow blocks have their payload touched ahead of the decoding workgroups, from where the first
