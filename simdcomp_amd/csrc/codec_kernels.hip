@@ -632,6 +632,8 @@ __global__ __launch_bounds__(BS) void k_unpack_fast(UnpackArgs a, uint32_t nwg =
       // It goes out behind the payload loads and without a branch of its own (no array -- one offset / base for every
       // block, as in the *_length forms -- reads g_nothing instead): a wait for it in front of the payload loads
       // would put two memory latencies in a row (measured: 80 -> 60-70 % of peak for widths 15..31).
+      // (The same load through the scalar unit, as the per-block-width kernel fetches its metadata: within +-0.5 points
+      // for 1..7 bits, -2..3 points for 8..16 bits, nothing from 17 on.)
       const size_t mine = tile * per_iter + (size_t)wv * 2 * U + (size_t)(lane % (2 * U));
       const uint32_t ms = load_global_as<uint32_t>(a.seeds ? reinterpret_cast<uintptr_t>(a.seeds + mine)
                                                            : reinterpret_cast<uintptr_t>(&g_nothing));
