@@ -720,7 +720,8 @@ __global__ __launch_bounds__(BS) void k_pack_fast(PackArgs a) {
       }
     }
     // Per-block metadata, every lane loading its own block's entry: the encoders are bound by vector-ALU work, and
-    // handing coalesced loads out through scalar registers (as the decoders do) costs them 3-6 points of HBM peak.
+    // handing coalesced loads out through scalar registers (as the decoders do) costs them 3-6 points of HBM peak;
+    // scalar loads of widths and offsets (as the per-block-width decoder has them) cost 4 %.
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const size_t blk = first + 2 * (size_t)u;

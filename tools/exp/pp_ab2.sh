@@ -12,7 +12,7 @@ for line in open(sys.argv[1]):
     kind, _, rest = line.partition(" ")
     if kind in ("mixed", "stream"):
         d = json.loads(rest)
-        print(kind, d.get("avg_bits"), {k: v["ms"] for k, v in d.items() if isinstance(v, dict) and k in ("unpack_mixed", "unpack_stream", "stream_decode", "stream_decode_plain", "pack_mixed")})
+        print(kind, d.get("avg_bits"), {k: v["ms"] for k, v in d.items() if isinstance(v, dict) and k in ("unpack_mixed", "unpack_stream", "stream_decode", "stream_decode_plain", "pack_mixed", "pack_stream", "stream_compress")})
 PY
-  timeout -k 10 200 python3 tools/exp/mixed_uniform.py 4 6 7 8 9 2>&1 | grep -v amdgpu.ids | tee gpurun_out/pp/$v.log
+  if [ -z "$PP_NO_UNIFORM" ]; then timeout -k 10 200 python3 tools/exp/mixed_uniform.py 4 6 7 8 9 2>&1 | grep -v amdgpu.ids | tee gpurun_out/pp/$v.log; fi
 done
