@@ -202,7 +202,9 @@ constexpr int QUERY_RUN_U = SC_QUERY_RUN_U;  // blocks per half-wave whose paylo
 template <int MODE, int WHAT, bool LAST4 = false>
 __global__ __launch_bounds__(256) void k_query_runs(QueryArgs a) {
   __shared__ u32x4 lds_pay[4][2][33];
-  __shared__ u32x4 lds_val[4][2 * QUERY_RUN_U][32];  // the decoded runs of one group of iterations, [2 * u + h]
+  // the decoded runs of one group of iterations, [2 * u + h]; 33 rows each, so that the runs start four banks apart:
+  // every lane's bisection begins at value 64 of its own run, and with runs 128 words apart all of those were one bank
+  __shared__ u32x4 lds_val[4][2 * QUERY_RUN_U][33];
   __shared__ uint32_t lds_head[4][QUERY_RUN + 1];  // lane of the first query of the wave's d-th run; [D] = 64
   constexpr int U = QUERY_RUN_U;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -385,6 +387,8 @@ __global__ __launch_bounds__(256) void k_query_runs(QueryArgs a) {
         if (my_turn) res_value = got;
       } else {
         const int length = my_len < 0 ? 0 : (my_len > 128 ? 128 : my_len);
+        // (for the differential search, whose values do not decrease here, a lower bound by fixed strides of 64, 32,
+        // .. 1, 1 has half the instructions of this loop and measured the same: the probes' LDS latency is what counts)
         int begin = 0, cnt = length;
 #pragma unroll
         for (int step_no = 0; step_no < 8; ++step_no) {  // 128 -> 0 in at most eight halvings

@@ -46,6 +46,8 @@ def main():
     T = int(total.item())
     arena = torch.empty(T + 16, dtype=torch.uint8, device=dev)
     back = torch.empty_like(ids)
+    if "mixed" in WHAT or any(k.startswith("query") for k in WHAT):
+        codec.pack_mixed(1, ids, bits, off, arena, initvalues=seeds, masked=False)
     if "mixed" in WHAT:
         for _ in range(2):
             codec.pack_mixed(1, ids, bits, off, arena, initvalues=seeds, masked=False)
@@ -58,6 +60,17 @@ def main():
             chained = codec.chain_offsets(strm, bits, off, stream_layout=True)
             codec.unpack_stream(1, strm, bits, off, nblk, initvalues=chained, out=back)
         assert torch.equal(back, ids)
+    for kind in ("query_random", "query_sorted"):
+        # 2^24 searches and selects, a random block each / the same batch in block order
+        if kind in WHAT:
+            qb = torch.randint(0, nblk, (1 << 24,), device=dev, generator=g)
+            if kind == "query_sorted":
+                qb = torch.sort(qb)[0]
+            keys = ids.view(-1, 128)[qb, torch.randint(0, 128, (1 << 24,), device=dev, generator=g)] + 1
+            slots = torch.randint(0, 128, (1 << 24,), dtype=torch.int32, device=dev, generator=g)
+            for _ in range(2):
+                codec.search(1, arena, keys, bits=bits, offsets=off, initvalues=seeds, query_blocks=qb)
+                codec.select(1, arena, slots, bits=bits, offsets=off, initvalues=seeds, query_blocks=qb)
     torch.cuda.synchronize()
     print("pmc workload done", LOG2N, WHAT)
 
