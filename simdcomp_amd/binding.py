@@ -49,6 +49,10 @@ DEVICE_API = {
     "simdcomp_hip_stream_decode": (C.c_int, [C.c_int, u32, vp, sz, sz, vp, vp, vp, vp]),
     "simdcomp_hip_select": (C.c_int, [C.c_int, u32, vp, vp, vp, vp, u32, C.c_int, vp, vp, sz, vp, vp]),
     "simdcomp_hip_search": (C.c_int, [C.c_int, u32, vp, vp, vp, vp, u32, C.c_int, vp, vp, vp, sz, vp, vp, vp, vp]),
+    "simdcomp_hip_block_directory_bytes": (sz, [sz]),
+    "simdcomp_hip_block_directory": (C.c_int, [u32, vp, vp, vp, sz, C.c_int, vp, vp]),
+    "simdcomp_hip_select_directory": (C.c_int, [C.c_int, vp, vp, vp, vp, sz, vp, vp]),
+    "simdcomp_hip_search_directory": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, sz, vp, vp, vp, vp]),
     "simdcomp_hip_scand1": (C.c_int, [u32, vp, vp, vp, vp, u32, C.c_int, sz, vp, vp]),
     "simdcomp_hip_pack_lanes": (C.c_int, [C.c_int, vp, vp, sz, u32, C.c_int, vp]),
     "simdcomp_hip_unpack_lanes": (C.c_int, [C.c_int, vp, vp, sz, u32, vp]),

@@ -243,6 +243,36 @@ def select(mode, payload, slots, bit=0, bits=None, offsets=None, initvalues=None
     return out
 
 
+def block_directory(bits, offsets, initvalues=None, initvalue=0, stream_layout=False):
+    """One 16-byte entry per block (payload position, width, initvalue) for select / search with directory=."""
+    nblk = bits.numel()
+    d = torch.empty(max(16, B.lib().simdcomp_hip_block_directory_bytes(nblk)), dtype=torch.uint8, device=bits.device)
+    B.check(B.lib().simdcomp_hip_block_directory(_s32(initvalue), B.ptr(initvalues), B.ptr(offsets), B.ptr(bits), nblk,
+                                                 int(stream_layout), B.ptr(d), _stream()), "block_directory")
+    return d
+
+
+def select_directory(mode, payload, directory, slots, query_blocks=None):
+    """simdcomp_hip_select with the blocks' metadata taken from a block_directory."""
+    nq = slots.numel()
+    out = torch.empty(nq, dtype=torch.int32, device=slots.device)
+    B.check(B.lib().simdcomp_hip_select_directory(mode, B.ptr(payload), B.ptr(directory), B.ptr(query_blocks), B.ptr(slots),
+                                                  nq, B.ptr(out), _stream()), "select_directory")
+    return out
+
+
+def search_directory(mode, payload, directory, keys, query_blocks=None, lengths=None, want_last4=False):
+    """simdcomp_hip_search with the blocks' metadata taken from a block_directory."""
+    nq = keys.numel()
+    pos = torch.empty(nq, dtype=torch.int32, device=keys.device)
+    val = torch.empty(nq, dtype=torch.int32, device=keys.device)
+    last4 = torch.empty(nq * 4, dtype=torch.int32, device=keys.device) if want_last4 else None
+    B.check(B.lib().simdcomp_hip_search_directory(mode, B.ptr(payload), B.ptr(directory), B.ptr(query_blocks), B.ptr(keys),
+                                                  B.ptr(lengths), nq, B.ptr(pos), B.ptr(val), B.ptr(last4), _stream()),
+            "search_directory")
+    return (pos, val, last4) if want_last4 else (pos, val)
+
+
 def search(mode, payload, keys, bit=0, bits=None, offsets=None, initvalues=None, initvalue=0, query_blocks=None,
            lengths=None, stream_layout=False, want_last4=False):
     """Batched simdsearchwithlengthd1 / simdsearchwithlengthFOR -> (positions int32[nq], values int32[nq][, last4])."""

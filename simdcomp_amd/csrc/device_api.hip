@@ -503,6 +503,57 @@ int simdcomp_hip_search(int mode, uint32_t initvalue, const uint32_t *d_initvalu
                   stream);
 }
 
+size_t simdcomp_hip_block_directory_bytes(size_t nblocks) { return nblocks * sc::DIRECTORY_ENTRY_BYTES; }
+
+int simdcomp_hip_block_directory(uint32_t initvalue, const uint32_t *d_initvalues, const uint64_t *d_payload_offsets,
+                                 const uint8_t *d_bits, size_t nblocks, int stream_layout, void *d_directory, void *stream) {
+  if (nblocks == 0) return SIMDCOMP_HIP_OK;
+  if (!d_payload_offsets || !d_bits || !d_directory) return fail(SIMDCOMP_HIP_ENULL, "NULL pointer");
+  if (!aligned16(d_directory)) return fail(SIMDCOMP_HIP_EALIGN, "directory not 16-byte aligned");
+  return SC_LAUNCH(sc::launch_block_directory(initvalue, d_initvalues, d_payload_offsets, d_bits, nblocks, stream_layout ? 1u : 0u,
+                                              d_directory, as_stream(stream)),
+                   "block directory launch");
+}
+
+namespace {
+int do_directory_query(int mode, int what, const void *d_payload, const void *d_directory, sc::QueryArgs a, void *stream) {
+  if (mode < 0 || mode > 2) return fail(SIMDCOMP_HIP_EMODE, "unknown mode");
+  if (a.nqueries == 0) return SIMDCOMP_HIP_OK;
+  if (!d_payload || !d_directory) return fail(SIMDCOMP_HIP_ENULL, "NULL pointer");
+  if (!aligned16(d_directory)) return fail(SIMDCOMP_HIP_EALIGN, "directory not 16-byte aligned");
+  a.payload = d_payload;
+  a.directory = d_directory;
+  return SC_LAUNCH(sc::launch_query(mode, what, a, as_stream(stream)), "query launch");
+}
+}  // namespace
+
+int simdcomp_hip_select_directory(int mode, const void *d_payload, const void *d_directory, const uint64_t *d_query_blocks,
+                                  const int32_t *d_slots, size_t nqueries, uint32_t *d_values_out, void *stream) {
+  if (nqueries && (!d_slots || !d_values_out)) return fail(SIMDCOMP_HIP_ENULL, "NULL pointer");
+  sc::QueryArgs a{};
+  a.query_blocks = d_query_blocks;
+  a.slots = d_slots;
+  a.nqueries = nqueries;
+  a.values_out = d_values_out;
+  return do_directory_query(mode, sc::Q_SELECT, d_payload, d_directory, a, stream);
+}
+
+int simdcomp_hip_search_directory(int mode, const void *d_payload, const void *d_directory, const uint64_t *d_query_blocks,
+                                  const uint32_t *d_keys, const int32_t *d_lengths, size_t nqueries, int32_t *d_positions_out,
+                                  uint32_t *d_values_out, uint32_t *d_last4_out, void *stream) {
+  if (nqueries && (!d_keys || !d_values_out || !d_positions_out)) return fail(SIMDCOMP_HIP_ENULL, "NULL pointer");
+  if (d_last4_out && mode != SIMDCOMP_HIP_D1) return fail(SIMDCOMP_HIP_EMODE, "the offset vector exists for d1 only");
+  sc::QueryArgs a{};
+  a.query_blocks = d_query_blocks;
+  a.keys = d_keys;
+  a.lengths = d_lengths;
+  a.nqueries = nqueries;
+  a.values_out = d_values_out;
+  a.positions_out = d_positions_out;
+  a.last4_out = d_last4_out;
+  return do_directory_query(mode, sc::Q_SEARCH, d_payload, d_directory, a, stream);
+}
+
 int simdcomp_hip_scand1(uint32_t initvalue, const uint32_t *d_initvalues, const void *d_payload,
                         const uint64_t *d_payload_offsets, const uint8_t *d_bits, uint32_t bit, int stream_layout,
                         size_t nblocks, uint32_t *d_last4_out, void *stream) {

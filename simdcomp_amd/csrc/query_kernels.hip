@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void k_query(QueryArgs a) {
 constexpr int QUERY_RUN = 64;
 constexpr int QUERY_RUN_U = SC_QUERY_RUN_U;  // blocks per half-wave whose payload loads are in flight together
 
-template <int MODE, int WHAT, bool LAST4 = false>
+template <int MODE, int WHAT, bool LAST4 = false, bool DIR = false>
 __global__ __launch_bounds__(256) void k_query_runs(QueryArgs a) {
   __shared__ u32x4 lds_pay[4][2][33];
   // the decoded runs of one group of iterations, [2 * u + h]; 33 rows each, so that the runs start four banks apart:
@@ -223,10 +223,21 @@ __global__ __launch_bounds__(256) void k_query_runs(QueryArgs a) {
   const int ln = load_global_as<int>(WHAT == Q_SEARCH && a.lengths ? reinterpret_cast<uintptr_t>(a.lengths + qc) : nothing);
   const int my_len = a.lengths ? ln : 128;
   const size_t blk = a.query_blocks ? (size_t)qb : qc;
-  // second fetch: the block's width, offset and seed (lanes of one run read the same entries: one request)
-  const uint8_t wb = load_global_as<uint8_t>(a.bits ? reinterpret_cast<uintptr_t>(a.bits + blk) : nothing);
-  const uint64_t po = load_global_as<uint64_t>(a.off ? reinterpret_cast<uintptr_t>(a.off + blk) : nothing);
-  const uint32_t sd = load_global_as<uint32_t>(MODE != MODE_PLAIN && a.seeds ? reinterpret_cast<uintptr_t>(a.seeds + blk) : nothing);
+  // second fetch: the block's width, offset and seed (lanes of one run read the same entries: one request), or its
+  // directory entry, which holds all three
+  uint8_t wb = 0;
+  uint64_t po = 0;
+  uint32_t sd = 0;
+  if constexpr (DIR) {
+    const u32x4 e = load_global_at(reinterpret_cast<uintptr_t>(a.directory) + DIRECTORY_ENTRY_BYTES * blk);
+    wb = (uint8_t)(e.y >> 24);
+    po = ((uint64_t)(e.y & 0xFFFFu) << 32) | e.x;
+    sd = e.z;
+  } else {
+    wb = load_global_as<uint8_t>(a.bits ? reinterpret_cast<uintptr_t>(a.bits + blk) : nothing);
+    po = load_global_as<uint64_t>(a.off ? reinterpret_cast<uintptr_t>(a.off + blk) : nothing);
+    sd = load_global_as<uint32_t>(MODE != MODE_PLAIN && a.seeds ? reinterpret_cast<uintptr_t>(a.seeds + blk) : nothing);
+  }
   // runs: a lane is a head when the lane before it asks for another block
   const uint32_t blk_lo = (uint32_t)blk, blk_hi = (uint32_t)((uint64_t)blk >> 32);
   const uint32_t prev_lo = (uint32_t)__shfl_up((int)blk_lo, 1, 64), prev_hi = (uint32_t)__shfl_up((int)blk_hi, 1, 64);
@@ -236,12 +247,19 @@ __global__ __launch_bounds__(256) void k_query_runs(QueryArgs a) {
   const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(heads >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)heads, 0u));
   if (head) lds_head[wv][below] = (uint32_t)lane;
   if (lane == 0) lds_head[wv][D] = QUERY_RUN;
-  uint32_t my_b = a.bits ? wb : a.bit;
+  uint32_t my_b = (DIR || a.bits) ? wb : a.bit;
   my_b = my_b > 32 ? 32 : my_b;
-  const uint64_t has_off = a.off ? ~0ull : 0ull;
-  const uint64_t my_base = reinterpret_cast<uintptr_t>(a.payload) + (po & has_off) + ((a.stream_layout ? blk + 1 : 0) & has_off) +
-                           ((blk * 16 * (size_t)my_b) & ~has_off);
-  const uint32_t my_seed = MODE == MODE_PLAIN ? 0u : (a.seeds ? sd : a.seed0);
+  uint64_t my_base;
+  uint32_t my_seed;
+  if constexpr (DIR) {
+    my_base = reinterpret_cast<uintptr_t>(a.payload) + po;
+    my_seed = MODE == MODE_PLAIN ? 0u : sd;
+  } else {
+    const uint64_t has_off = a.off ? ~0ull : 0ull;
+    my_base = reinterpret_cast<uintptr_t>(a.payload) + (po & has_off) + ((a.stream_layout ? blk + 1 : 0) & has_off) +
+              ((blk * 16 * (size_t)my_b) & ~has_off);
+    my_seed = MODE == MODE_PLAIN ? 0u : (a.seeds ? sd : a.seed0);
+  }
   const uint32_t my_run = below + (head ? 1u : 0u) - 1u;  // the run this lane's query belongs to
   uint32_t res_value = 0;
   int res_pos = 0;
@@ -435,21 +453,49 @@ __global__ __launch_bounds__(256) void k_query_runs(QueryArgs a) {
 #define SC_QUERY_RUNS 1
 #endif
 
+// One directory entry per block (layout: query_kernels.h).  An offset that does not fit 48 bits (no device memory is
+// that large) becomes a zero-width block with seed 0, which is never dereferenced; word 3 marks it.
+__global__ __launch_bounds__(256) void k_block_directory(uint32_t seed0, const uint32_t *seeds, const uint64_t *off,
+                                                         const uint8_t *bits, size_t nblocks, uint32_t stream_layout,
+                                                         u32x4 *directory) {
+  const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= nblocks) return;
+  uint32_t b = bits[k];
+  b = b > 32 ? 32 : b;
+  const uint64_t at = off[k] + (stream_layout ? k + 1 : 0);
+  const uint32_t seed = seeds ? seeds[k] : seed0;
+  const bool fits = at <= DIRECTORY_MAX_OFFSET;
+  directory[k] = fits ? u32x4{(uint32_t)at, (uint32_t)(at >> 32) | (b << 24), seed, 0u} : u32x4{0u, 0u, 0u, 1u};
+}
+
+hipError_t launch_block_directory(uint32_t seed0, const uint32_t *seeds, const uint64_t *off, const uint8_t *bits, size_t nblocks,
+                                  uint32_t stream_layout, void *directory, hipStream_t st) {
+  if (nblocks == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_block_directory, dim3((unsigned)((nblocks + 255) / 256)), dim3(256), 0, st, seed0, seeds, off, bits, nblocks,
+                     stream_layout, static_cast<u32x4 *>(directory));
+  return hipGetLastError();
+}
+
 hipError_t launch_query(int mode, int what, const QueryArgs &a, hipStream_t st) {
   if (a.nqueries == 0) return hipSuccess;
-  if (SC_QUERY_RUNS && what != Q_SCAN) {
+  if (a.directory && what == Q_SCAN) return hipErrorInvalidValue;
+  if ((SC_QUERY_RUNS || a.directory) && what != Q_SCAN) {
     const dim3 g((unsigned)((a.nqueries + 4 * QUERY_RUN - 1) / (4 * QUERY_RUN))), t(256);
-#define SC_QR(MODE_, WHAT_) hipLaunchKernelGGL((k_query_runs<MODE_, WHAT_>), g, t, 0, st, a)
+#define SC_QR(MODE_, WHAT_, LAST4_)                                                          \
+  do {                                                                                       \
+    if (a.directory) hipLaunchKernelGGL((k_query_runs<MODE_, WHAT_, LAST4_, true>), g, t, 0, st, a);  \
+    else hipLaunchKernelGGL((k_query_runs<MODE_, WHAT_, LAST4_, false>), g, t, 0, st, a);    \
+  } while (0)
     if (mode == MODE_D1) {
-      if (what == Q_SELECT) SC_QR(MODE_D1, Q_SELECT);
-      else if (a.last4_out) hipLaunchKernelGGL((k_query_runs<MODE_D1, Q_SEARCH, true>), g, t, 0, st, a);
-      else SC_QR(MODE_D1, Q_SEARCH);
+      if (what == Q_SELECT) SC_QR(MODE_D1, Q_SELECT, false);
+      else if (a.last4_out) SC_QR(MODE_D1, Q_SEARCH, true);
+      else SC_QR(MODE_D1, Q_SEARCH, false);
     } else if (mode == MODE_FOR) {
-      if (what == Q_SELECT) SC_QR(MODE_FOR, Q_SELECT);
-      else SC_QR(MODE_FOR, Q_SEARCH);
+      if (what == Q_SELECT) SC_QR(MODE_FOR, Q_SELECT, false);
+      else SC_QR(MODE_FOR, Q_SEARCH, false);
     } else {
-      if (what == Q_SELECT) SC_QR(MODE_PLAIN, Q_SELECT);
-      else SC_QR(MODE_PLAIN, Q_SEARCH);
+      if (what == Q_SELECT) SC_QR(MODE_PLAIN, Q_SELECT, false);
+      else SC_QR(MODE_PLAIN, Q_SEARCH, false);
     }
 #undef SC_QR
     return hipGetLastError();

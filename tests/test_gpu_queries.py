@@ -99,6 +99,8 @@ def test_batched_queries_mixed_widths(dev, orc, order):
     the same batch sorted by block (neighbouring queries on one block share its decode: runs of every length,
     across the 64-query groups the kernel works in); a batch on a handful of blocks (runs far longer than a group);
     and sorted downwards (runs, but no ascending order to lean on)."""
+    import torch
+
     nblk, nq = 3000, 20011
     x, seeds, bits, off, arena, stream = mixed_corpus(dev, nblk, 61)
     h_bits, h_off, h_seeds, h_arena = bits.cpu().numpy(), off.cpu().numpy(), u32(seeds), arena.cpu().numpy()
@@ -135,6 +137,16 @@ def test_batched_queries_mixed_widths(dev, orc, order):
                                 int(u32(val)[q]), int(want_val[q])) for q in bad[:5]]
         last4 = dev.scand1(payload, nblk, bits=bits, offsets=off, initvalues=seeds, stream_layout=layout)
         assert np.array_equal(u32(last4).reshape(nblk, 4), x.reshape(nblk, 128)[:, 124:])
+        # the same queries with the blocks' metadata taken from a block directory
+        directory = dev.block_directory(bits, off, initvalues=seeds, stream_layout=layout)
+        got = dev.select_directory(D1, payload, directory, to_dev(slots), query_blocks=to_dev(qb))
+        assert np.array_equal(u32(got), want_sel)
+        dpos, dval = dev.search_directory(D1, payload, directory, to_dev(keys), query_blocks=to_dev(qb), lengths=to_dev(lengths))
+        assert np.array_equal(dpos.cpu().numpy(), want_pos) and np.array_equal(u32(dval), want_val)
+        _, _, l4 = dev.search(D1, payload, to_dev(keys), bits=bits, offsets=off, initvalues=seeds, query_blocks=to_dev(qb),
+                              stream_layout=layout, want_last4=True)
+        _, _, dl4 = dev.search_directory(D1, payload, directory, to_dev(keys), query_blocks=to_dev(qb), want_last4=True)
+        assert torch.equal(l4, dl4)
 
 
 @pytest.mark.parametrize("bit", [0, 1, 5, 13, 31, 32])
@@ -194,6 +206,10 @@ def test_batched_queries_for_and_plain_with_runs(dev, orc, mode):
         got = dev.select(mode, arena, to_dev(slots), **kw)
         assert np.array_equal(u32(got), xs[qb.astype(np.int64), slots]), (mode, order)
         pos, val = dev.search(mode, arena, to_dev(keys), lengths=to_dev(lengths), **kw)
+        directory = dev.block_directory(bits, off, initvalues=kw.get("initvalues"))
+        assert torch.equal(got, dev.select_directory(mode, arena, directory, to_dev(slots), query_blocks=to_dev(qb)))
+        dpos, dval = dev.search_directory(mode, arena, directory, to_dev(keys), query_blocks=to_dev(qb), lengths=to_dev(lengths))
+        assert torch.equal(pos, dpos) and torch.equal(val, dval)
         pos, val = pos.cpu().numpy(), u32(val)
         for q in range(0, nq, 7):
             k = int(qb[q])

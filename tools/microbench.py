@@ -183,6 +183,17 @@ def query(n, nblk, reps):
         res["search_" + name] = {"queries": nq, "ms": round(t * 1e3, 4), "Gquery/s": round(nq / t / 1e9, 2), "GB/s": round(by / t / 1e9, 1)}
         t = timeit(lambda: codec.select(1, arena, slots, bits=bits, offsets=off, initvalues=seeds, query_blocks=qb), reps)
         res["select_" + name] = {"queries": nq, "ms": round(t * 1e3, 4), "Gquery/s": round(nq / t / 1e9, 2)}
+        if name in ("random_blocks", "sorted_blocks"):
+            # the same with a block directory (one 16-byte metadata entry per block instead of three arrays)
+            directory = codec.block_directory(bits, off, initvalues=seeds)
+            dpos, dval = codec.search_directory(1, arena, directory, keys, query_blocks=qb)
+            assert torch.equal(dpos, pos) and torch.equal(dval, val)
+            t = timeit(lambda: codec.search_directory(1, arena, directory, keys, query_blocks=qb), reps)
+            res["search_directory_" + name] = {"queries": nq, "ms": round(t * 1e3, 4), "Gquery/s": round(nq / t / 1e9, 2)}
+            t = timeit(lambda: codec.select_directory(1, arena, directory, slots, query_blocks=qb), reps)
+            res["select_directory_" + name] = {"queries": nq, "ms": round(t * 1e3, 4), "Gquery/s": round(nq / t / 1e9, 2)}
+            t = timeit(lambda: codec.block_directory(bits, off, initvalues=seeds), reps)
+            res["block_directory"] = {"blocks": nblk, "ms": round(t * 1e3, 4)}
     print("query", json.dumps(res), flush=True)
 
 
