@@ -357,6 +357,18 @@ def test_argument_errors(dev):
     assert L.simdcomp_hip_unpackd1(None, out.data_ptr(), x.data_ptr(), 1, 5, None) == -3
     assert b"NULL" in L.simdcomp_hip_last_error()
     assert L.simdcomp_hip_pack(None, None, 0, 5, 0, None) == 0  # empty batch is fine
+    # the directory forms of the queries
+    d, o, q = out.data_ptr(), x.data_ptr(), x.data_ptr()
+    assert L.simdcomp_hip_block_directory(0, None, None, d, 4, 0, d, None) == -3
+    assert L.simdcomp_hip_block_directory(0, None, o, d, 4, 0, d + 8, None) == -2
+    assert L.simdcomp_hip_block_directory(0, None, None, None, 0, 0, None, None) == 0
+    assert L.simdcomp_hip_block_directory_bytes(10) == 160
+    assert L.simdcomp_hip_select_directory(9, d, d, None, q, 4, q, None) == -4
+    assert L.simdcomp_hip_select_directory(1, d, None, None, q, 4, q, None) == -3
+    assert L.simdcomp_hip_select_directory(1, d, d + 4, None, q, 4, q, None) == -2
+    assert L.simdcomp_hip_search_directory(2, d, d, None, q, None, 4, q, q, q, None) == -4  # the offset vector is d1's
+    assert L.simdcomp_hip_search_directory(1, d, d, None, None, None, 4, q, q, None, None) == -3
+    assert L.simdcomp_hip_search_directory(1, None, None, None, None, None, 0, None, None, None, None) == 0
 
 
 def test_partition_and_checksum(dev):
